@@ -1,0 +1,466 @@
+"""CPU oracle for the contrastive-alignment hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A plain numpy restatement (fp32 storage, BLAS matmuls) of the reference algorithm for the path
+named by BASELINE.json `north_star`.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this file; the product (prot2text-v2-esm3_amd/) never does and fails
+loudly when its HIP library is missing.
+
+Parity pinning: the reference ships no tests and no golden vectors, so this
+oracle is pinned against outputs of the reference itself, generated in the build container by
+tests/golden/make_golden.py (which imports /root/reference and HuggingFace transformers 5.15.0)
+and committed as tests/golden/*.npz; tests/test_oracle_golden.py checks every function here
+against them.
+
+Each function cites what it restates.  "HF" = site-packages/transformers (third-party code the
+reference delegates the tower arithmetic to; reference pins transformers==4.40.2 in README.md:42-49,
+the container has 5.15.0 -- the math on this path is unchanged).
+    REF   = /root/reference
+    ESM   = transformers/models/esm/modeling_esm.py
+    LLAMA = transformers/models/llama/modeling_llama.py
+    ROPE  = transformers/modeling_rope_utils.py
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import numpy as np
+from scipy.special import erf as _erf
+
+F32 = np.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# precision model: identity (fp32 oracle) or bf16 rounding at the points where the HIP bf16 path
+# stores bf16 (weights, GEMM inputs, attention probabilities).  Accumulation is fp32 either way.
+# ---------------------------------------------------------------------------------------------
+def _bf16(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
+    return r.astype(np.uint32).view(F32).reshape(x.shape)
+
+
+class Precision:
+    def __init__(self, kind: str = "f32"):
+        assert kind in ("f32", "bf16")
+        self.kind = kind
+
+    def q(self, x):           # "quantise a stored activation / weight"
+        return x if self.kind == "f32" else _bf16(x)
+
+
+FP32 = Precision("f32")
+BF16 = Precision("bf16")
+
+
+# ---------------------------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------------------------
+def gelu_erf(x):
+    """ESM:82-86 `x * 0.5 * (1 + erf(x / sqrt(2)))`; also torch.nn.GELU() (exact) used by the
+    adapter, REF models/modeling_esm2llama_instruct.py:54."""
+    x = x.astype(F32, copy=False)
+    return (x * F32(0.5) * (F32(1.0) + _erf(x / F32(math.sqrt(2.0))).astype(F32))).astype(F32)
+
+
+def gelu_erf_grad(x):
+    x = x.astype(F32, copy=False)
+    cdf = F32(0.5) * (F32(1.0) + _erf(x / F32(math.sqrt(2.0))).astype(F32))
+    pdf = np.exp(-0.5 * x * x).astype(F32) * F32(1.0 / math.sqrt(2.0 * math.pi))
+    return (cdf + x * pdf).astype(F32)
+
+
+def layer_norm(x, w, b, eps):
+    """torch.nn.LayerNorm (ESM:418,429,480,518,529,553): biased variance, eps inside the sqrt."""
+    x = x.astype(F32, copy=False)
+    mu = x.mean(-1, keepdims=True, dtype=F32)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps)) * w + b).astype(F32)
+
+
+def rms_norm(x, w, eps):
+    """LLAMA:62-67: fp32 variance, x * rsqrt(var + eps), weight multiplied last."""
+    x = x.astype(F32, copy=False)
+    var = (x * x).mean(-1, keepdims=True, dtype=F32)
+    return (w * (x / np.sqrt(var + F32(eps)))).astype(F32)
+
+
+def rotate_half(x):
+    """ESM:48-52 / LLAMA:130-134."""
+    h = x.shape[-1] // 2
+    return np.concatenate([-x[..., h:], x[..., :h]], axis=-1)
+
+
+def rope_cos_sin(inv_freq, positions):
+    """ESM:146-160 / LLAMA:108-127: freqs = pos x inv_freq, emb = cat(freqs, freqs), fp32."""
+    freqs = positions.astype(F32)[:, None] * inv_freq.astype(F32)[None, :]
+    emb = np.concatenate([freqs, freqs], axis=-1)
+    return np.cos(emb).astype(F32), np.sin(emb).astype(F32)
+
+
+def default_inv_freq(theta: float, dim: int):
+    """ESM:127-138 / LLAMA:87-106: 1 / theta^(2i/dim)."""
+    return (1.0 / (F32(theta) ** (np.arange(0, dim, 2, dtype=F32) / F32(dim)))).astype(F32)
+
+
+def llama3_inv_freq(theta, dim, factor, low_freq_factor, high_freq_factor, original_max_pos):
+    """ROPE:580-662 `_compute_llama3_parameters` (fp32 throughout, as torch computes it)."""
+    inv = default_inv_freq(theta, dim)
+    low_wl = F32(original_max_pos / low_freq_factor)
+    high_wl = F32(original_max_pos / high_freq_factor)
+    wavelen = (F32(2.0 * math.pi) / inv).astype(F32)
+    inv_l = np.where(wavelen > low_wl, inv / F32(factor), inv).astype(F32)
+    smooth = ((F32(original_max_pos) / wavelen - F32(low_freq_factor))
+              / F32(high_freq_factor - low_freq_factor)).astype(F32)
+    smoothed = ((F32(1.0) - smooth) * inv_l / F32(factor) + smooth * inv_l).astype(F32)
+    medium = (~(wavelen < high_wl)) & (~(wavelen > low_wl))
+    return np.where(medium, smoothed, inv_l).astype(F32)
+
+
+def softmax_rows(s):
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m, dtype=F32)
+    return (e / e.sum(-1, keepdims=True, dtype=F32)).astype(F32)
+
+
+NEG = F32(np.finfo(np.float32).min)
+
+
+# ---------------------------------------------------------------------------------------------
+# ESM2 encoder  (REF models/modeling_esm2llama_instruct.py:175-185 -> HF EsmModel.forward ESM:685-755)
+# ---------------------------------------------------------------------------------------------
+def esm2_embeddings(spec, W, ids, mask, prefix=""):
+    """ESM:224-271 with position_embedding_type='rotary' (no absolute table): gather, zero <mask>
+    tokens, scale by (1-0.12)/(1-observed mask ratio), multiply by attention_mask."""
+    emb = W[prefix + "embeddings.word_embeddings.weight"][ids]            # (B,T,H)
+    if spec.token_dropout:
+        is_mask = (ids == spec.mask_token_id)
+        emb = np.where(is_mask[..., None], F32(0.0), emb)
+        src_len = mask.sum(-1).astype(F32)
+        ratio = is_mask.sum(-1).astype(F32) / src_len
+        emb = emb * F32(1.0 - 0.15 * 0.8) / (F32(1.0) - ratio)[:, None, None]
+    if spec.emb_layer_norm_before:
+        emb = layer_norm(emb, W[prefix + "embeddings.layer_norm.weight"],
+                         W[prefix + "embeddings.layer_norm.bias"], spec.layer_norm_eps)
+    emb = emb * mask[..., None].astype(F32)
+    return emb.astype(F32)
+
+
+def esm2_layer(spec, W, i, x, key_bias, cos, sin, prec: Precision = FP32, prefix=""):
+    """One pre-LN block, ESM:420-439 (attention) + ESM:517-521 (FFN).
+    q is scaled by d^-1/2 BEFORE rotary and SDPA runs with scale 1.0 (ESM:345,374)."""
+    B, T, H = x.shape
+    nh, d = spec.num_attention_heads, spec.head_dim
+    p = f"{prefix}encoder.layer.{i}."
+    q_ = prec.q
+    h = q_(layer_norm(x, W[p + "attention.LayerNorm.weight"], W[p + "attention.LayerNorm.bias"],
+                      spec.layer_norm_eps))
+    h2 = h.reshape(B * T, H)
+
+    def lin(name, inp):
+        return inp @ q_(W[p + name + ".weight"]).T + W[p + name + ".bias"]
+
+    q = lin("attention.self.query", h2).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+    k = lin("attention.self.key", h2).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+    v = lin("attention.self.value", h2).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+    q = q * F32(d ** -0.5)
+    q = q * cos + rotate_half(q) * sin                                    # ESM:74-79 (fp32)
+    k = k * cos + rotate_half(k) * sin
+    q, k, v = q_(q), q_(k), q_(v)
+    s = np.einsum("bhqd,bhkd->bhqk", q, k, optimize=True).astype(F32) + key_bias   # ESM:310-317
+    pr = q_(softmax_rows(s))
+    o = np.einsum("bhqk,bhkd->bhqd", pr, v, optimize=True).astype(F32)
+    o = q_(o.transpose(0, 2, 1, 3).reshape(B * T, H))
+    x = x + lin("attention.output.dense", o).reshape(B, T, H)               # ESM:399-409
+    h = q_(layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], spec.layer_norm_eps))
+    f = q_(gelu_erf(lin("intermediate.dense", h.reshape(B * T, H))))         # ESM:442-450
+    x = x + lin("output.dense", f).reshape(B, T, H)                          # ESM:453-463
+    return x.astype(F32)
+
+
+def esm2_forward(spec, W, ids, mask, prec: Precision = FP32, prefix="", layers=None):
+    """HF EsmModel(add_pooling_layer=False).forward -> last_hidden_state (B,T,H)."""
+    if spec.position_embedding_type != "rotary":
+        raise ValueError("only rotary ESM2 checkpoints are on this path")
+    ids = np.asarray(ids); mask = np.asarray(mask)
+    B, T = ids.shape
+    x = esm2_embeddings(spec, W, ids, mask, prefix)
+    # bidirectional key-padding mask (ESM:758-788): additive dtype-min on padded KEYS only
+    key_bias = np.where(mask[:, None, None, :] != 0, F32(0.0), NEG).astype(F32)
+    inv = default_inv_freq(spec.rope_theta, spec.head_dim)
+    cos, sin = rope_cos_sin(inv, np.arange(T))                            # ESM:731-735
+    n = spec.num_hidden_layers if layers is None else layers
+    for i in range(n):
+        x = esm2_layer(spec, W, i, x, key_bias, cos, sin, prec, prefix)
+    if layers is None:
+        x = layer_norm(x, W[prefix + "encoder.emb_layer_norm_after.weight"],
+                       W[prefix + "encoder.emb_layer_norm_after.bias"], spec.layer_norm_eps)  # ESM:552-553
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# ModalityAdapter  (REF models/modeling_esm2llama_instruct.py:45-68), eval mode / dropout p = 0
+# ---------------------------------------------------------------------------------------------
+def l2_normalize(x, eps=1e-12):
+    """torch.nn.functional.normalize(p=2, dim=-1): x / max(||x||, eps)."""
+    x = x.astype(F32, copy=False)
+    n = np.sqrt((x * x).sum(-1, keepdims=True, dtype=F32))
+    return (x / np.maximum(n, F32(eps))).astype(F32)
+
+
+def adapter_forward(W, x, prec: Precision = FP32, prefix="", keep=None):
+    """normalize(gelu(fc2(gelu(fc1(x)))))  -- ln1/ln2 exist but are unused (REF :56-57)."""
+    q_ = prec.q
+    shp = x.shape
+    x2 = q_(x.reshape(-1, shp[-1]).astype(F32))
+    z1 = x2 @ q_(W[prefix + "fc1.weight"]).T + W[prefix + "fc1.bias"]
+    h1 = q_(gelu_erf(z1))
+    z2 = h1 @ q_(W[prefix + "fc2.weight"]).T + W[prefix + "fc2.bias"]
+    g2 = gelu_erf(z2)
+    y = l2_normalize(g2)
+    if keep is not None:
+        keep.update(x2=x2, z1=z1, h1=h1, z2=z2, g2=g2)
+    return y.reshape(*shp[:-1], -1)
+
+
+def adapter_backward(W, keep, dy, prec: Precision = FP32, prefix=""):
+    """Manual backward of adapter_forward w.r.t. fc1/fc2 weight and bias (the only tensors that
+    receive gradients in the reference's contrastive stage, train_contrast.py:186-187)."""
+    q_ = prec.q
+    g2, z2, h1, z1, x2 = keep["g2"], keep["z2"], keep["h1"], keep["z1"], keep["x2"]
+    dy = dy.reshape(g2.shape).astype(F32)
+    n = np.maximum(np.sqrt((g2 * g2).sum(-1, keepdims=True, dtype=F32)), F32(1e-12))
+    y = g2 / n
+    dg2 = (dy - y * (dy * y).sum(-1, keepdims=True, dtype=F32)) / n
+    dz2 = q_(dg2 * gelu_erf_grad(z2))
+    grads = {prefix + "fc2.weight": dz2.T @ h1, prefix + "fc2.bias": dz2.sum(0, dtype=F32)}
+    dh1 = dz2 @ q_(W[prefix + "fc2.weight"])
+    dz1 = q_(dh1 * gelu_erf_grad(z1))
+    grads[prefix + "fc1.weight"] = dz1.T @ x2
+    grads[prefix + "fc1.bias"] = dz1.sum(0, dtype=F32)
+    return {k: v.astype(F32) for k, v in grads.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# Llama text tower up to hidden_states[k]  (REF scripts/train_contrast.py:284-304 -> LLAMA:367-417)
+# ---------------------------------------------------------------------------------------------
+def llama_inv_freq(spec):
+    if spec.rope_type == "llama3":
+        return llama3_inv_freq(spec.rope_theta, spec.head_dim, spec.rope_factor, spec.rope_low_freq_factor,
+                               spec.rope_high_freq_factor, spec.rope_original_max_position_embeddings)
+    return default_inv_freq(spec.rope_theta, spec.head_dim)
+
+
+def llama_layer(spec, W, i, x, bias, cos, sin, prec: Precision = FP32, prefix=""):
+    """LLAMA:296-324 decoder layer; attention LLAMA:191-213,254-281 (GQA by repeat_kv, fp32 softmax)."""
+    B, T, H = x.shape
+    nh, nkv, d = spec.num_attention_heads, spec.num_key_value_heads, spec.head_dim
+    p = f"{prefix}model.layers.{i}."
+    q_ = prec.q
+    h = q_(rms_norm(x, W[p + "input_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H)
+    q = (h @ q_(W[p + "self_attn.q_proj.weight"]).T).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+    k = (h @ q_(W[p + "self_attn.k_proj.weight"]).T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+    v = (h @ q_(W[p + "self_attn.v_proj.weight"]).T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+    q = q * cos + rotate_half(q) * sin
+    k = k * cos + rotate_half(k) * sin
+    q, k, v = q_(q), q_(k), q_(v)
+    rep = nh // nkv
+    k = np.repeat(k, rep, axis=1)
+    v = np.repeat(v, rep, axis=1)
+    s = np.einsum("bhqd,bhkd->bhqk", q, k, optimize=True).astype(F32) * F32(d ** -0.5) + bias
+    pr = q_(softmax_rows(s))
+    o = np.einsum("bhqk,bhkd->bhqd", pr, v, optimize=True).astype(F32)
+    o = q_(o.transpose(0, 2, 1, 3).reshape(B * T, nh * d))
+    x = x + (o @ q_(W[p + "self_attn.o_proj.weight"]).T).reshape(B, T, H)
+    h = q_(rms_norm(x, W[p + "post_attention_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H)
+    g = h @ q_(W[p + "mlp.gate_proj.weight"]).T
+    u = h @ q_(W[p + "mlp.up_proj.weight"]).T
+    a = q_((g / (F32(1.0) + np.exp(-g, dtype=F32))) * u)                  # SiLU(g) * u, LLAMA:174-176
+    x = x + (a @ q_(W[p + "mlp.down_proj.weight"]).T).reshape(B, T, H)
+    return x.astype(F32)
+
+
+def llama_hidden_state(spec, W, ids, mask, k: int = 16, prec: Precision = FP32, prefix=""):
+    """`outputs.hidden_states[k]` of LlamaModel(..., output_hidden_states=True)
+    (train_contrast.py:294-304).  Index k < L is the residual stream after k layers; index L is the
+    post-final-RMSNorm last_hidden_state (transformers/utils/output_capturing.py:269-277)."""
+    ids = np.asarray(ids); mask = np.asarray(mask)
+    B, T = ids.shape
+    L = spec.num_hidden_layers
+    if not 0 <= k <= L:
+        raise IndexError(f"hidden_states[{k}] out of range for {L} layers")
+    x = W[prefix + "model.embed_tokens.weight"][ids].astype(F32)             # LLAMA:381
+    # causal AND key-padding (LLAMA:391-397 create_causal_mask): allowed(i,j) = j <= i and mask[j]
+    allowed = np.tril(np.ones((T, T), dtype=bool))[None, None] & (mask[:, None, None, :] != 0)
+    bias = np.where(allowed, F32(0.0), NEG).astype(F32)
+    cos, sin = rope_cos_sin(llama_inv_freq(spec), np.arange(T))
+    for i in range(k):
+        x = llama_layer(spec, W, i, x, bias, cos, sin, prec, prefix)
+    if k == L:
+        x = rms_norm(x, W[prefix + "model.norm.weight"], spec.rms_norm_eps)
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# readout / loss  (REF scripts/train_contrast.py)
+# ---------------------------------------------------------------------------------------------
+def readout_embeddings(emb, mask, readout_fn: str):
+    """REF scripts/train_contrast.py:198-248 ("last" :207-215, "mean" :217-221, "std" :223-235
+    population std with no eps, "mix" :237-248 = cat(mean, std))."""
+    emb = emb.astype(F32, copy=False)
+    if readout_fn == "last":
+        idx = mask.sum(1).astype(np.int64) - 1
+        return emb[np.arange(emb.shape[0]), idx, :]
+    m = mask.astype(F32)[..., None]
+    cnt = mask.sum(1, keepdims=True).astype(F32)
+    mean = (emb * m).sum(1, dtype=F32) / cnt
+    if readout_fn == "mean":
+        return mean.astype(F32)
+    diff = emb - mean[:, None, :]
+    std = np.sqrt((diff * diff * m).sum(1, dtype=F32) / cnt).astype(F32)
+    if readout_fn == "std":
+        return std
+    if readout_fn == "mix":
+        return np.concatenate([mean, std], axis=1).astype(F32)
+    raise ValueError(readout_fn)
+
+
+def readout_backward(emb, mask, readout_fn: str, dout):
+    """d(readout)/d(emb) applied to dout -- used for the adapter gradients."""
+    emb = emb.astype(F32, copy=False)
+    B, T, D = emb.shape
+    m = mask.astype(F32)[..., None]
+    cnt = mask.sum(1, keepdims=True).astype(F32)[..., None]
+    if readout_fn == "last":
+        g = np.zeros_like(emb)
+        idx = mask.sum(1).astype(np.int64) - 1
+        g[np.arange(B), idx, :] = dout
+        return g
+    if readout_fn == "mean":
+        return (m * dout[:, None, :] / cnt).astype(F32)
+    mean = (emb * m).sum(1, keepdims=True, dtype=F32) / cnt
+    diff = emb - mean
+    var = (diff * diff * m).sum(1, keepdims=True, dtype=F32) / cnt
+    std = np.sqrt(var)
+    if readout_fn == "std":
+        dmean, dstd = None, dout[:, None, :]
+    else:
+        dmean, dstd = dout[:, None, :D], dout[:, None, D:]
+    # std = sqrt(sum m (x-mean)^2 / cnt): d/dx_t = m_t (x_t-mean)/(cnt std) (the mean-path term
+    # -(sum m diff)/cnt vanishes because sum_t m_t diff_t = 0)
+    g = dstd * m * diff / (cnt * std)
+    if dmean is not None:
+        g = g + m * dmean / cnt
+    return g.astype(F32)
+
+
+def infonce_segmented(seg_out1, batch_out2, labels, temperature: float = 0.05, return_grad=False):
+    """SegmentedBatchInfoNCELoss.forward, REF scripts/train_contrast.py:100-114:
+    logits = P T^T / tau;  loss = -mean_i log(exp(l[i, y_i]) / sum_j exp(l[i, j]))  (rows only)."""
+    p = seg_out1.astype(F32); t = batch_out2.astype(F32)
+    logits = (p @ t.T) / F32(temperature)
+    e = np.exp(logits, dtype=F32)
+    den = e.sum(1, dtype=F32)
+    num = e[np.arange(p.shape[0]), labels]
+    loss = F32(-np.log(num / den, dtype=F32).mean(dtype=F32))
+    if not return_grad:
+        return loss
+    sm = e / den[:, None]
+    sm[np.arange(p.shape[0]), labels] -= F32(1.0)
+    dlogits = sm / F32(p.shape[0])
+    dp = (dlogits @ t) / F32(temperature)
+    return loss, dp.astype(F32), logits
+
+
+def infonce_batch(out1, out2, temperature: float = 0.05):
+    """BatchInfoNCELoss.forward, REF scripts/train_contrast.py:86-91 (labels = diagonal)."""
+    return infonce_segmented(out1, out2, np.arange(out1.shape[0]), temperature)
+
+
+def l2_normalize_backward(x, dy, eps=1e-12):
+    n = np.maximum(np.sqrt((x * x).sum(-1, keepdims=True, dtype=F32)), F32(eps))
+    y = x / n
+    return ((dy - y * (dy * y).sum(-1, keepdims=True, dtype=F32)) / n).astype(F32)
+
+
+# ---------------------------------------------------------------------------------------------
+# the contrastive step  (REF scripts/train_contrast.py:313-379 teacher_forcing_forward_pass)
+# ---------------------------------------------------------------------------------------------
+def protein_embeddings(esm_spec, W, prot_ids, prot_mask, readout="mix", ones_mask=False,
+                       prec: Precision = FP32, keep=None):
+    """Esm2LlamaInstructForCausalLM.forward(return_adapter_outputs=True) (REF models/...:175-193)
+    -> readout -> F.normalize (train_contrast.py:361-365).  `ones_mask=True` reproduces the fork's
+    all-ones readout mask (train_contrast.py:269-275)."""
+    enc = esm2_forward(esm_spec, W, prot_ids, prot_mask, prec, prefix="esm_encoder.")
+    ad = adapter_forward(W, enc, prec, prefix="adapter.", keep=keep)
+    rmask = np.ones_like(prot_mask) if ones_mask else prot_mask
+    pooled = readout_embeddings(ad, rmask, readout)
+    if keep is not None:
+        keep.update(enc=enc, adapter_out=ad, rmask=rmask, pooled=pooled)
+    return l2_normalize(pooled)
+
+
+def text_embeddings(llama_spec, W, text_ids, text_mask, layer=16, readout="mix", prec: Precision = FP32):
+    """get_description_embeddings (train_contrast.py:284-310) + F.normalize (:354)."""
+    hs = llama_hidden_state(llama_spec, W, text_ids, text_mask, layer, prec, prefix="llama_decoder.")
+    return l2_normalize(readout_embeddings(hs, text_mask, readout))
+
+
+def contrastive_loss(p_norm, t_norm, num_segments: int = 1, temperature: float = 0.05,
+                     label_offset: int = 0):
+    """Loop of train_contrast.py:356-379: mean over segments of the segmented InfoNCE.  Rows of
+    p_norm beyond segment_size*num_segments are dropped (as the reference does, :337-343)."""
+    B = p_norm.shape[0]
+    seg = B // num_segments
+    acc = F32(0.0)
+    for s in range(num_segments):
+        labels = np.arange(s * seg, (s + 1) * seg) + label_offset
+        acc = acc + infonce_segmented(p_norm[s * seg:(s + 1) * seg], t_norm, labels, temperature)
+    return F32(acc / F32(num_segments))
+
+
+def contrastive_step(esm_spec, llama_spec, W, prot_ids, prot_mask, text_ids, text_mask, *,
+                     layer=16, readout="mix", ones_mask=False, num_segments=1, temperature=0.05,
+                     prec: Precision = FP32, with_grads=False):
+    """Forward (+ adapter gradients) of one contrastive step.  Returns a dict with the normalised
+    pooled embeddings, the loss and, if requested, d loss / d adapter.{fc1,fc2}.{weight,bias}."""
+    keep = {} if with_grads else None
+    t = text_embeddings(llama_spec, W, text_ids, text_mask, layer, readout, prec)
+    p = protein_embeddings(esm_spec, W, prot_ids, prot_mask, readout, ones_mask, prec, keep)
+    out = {"protein": p, "text": t, "loss": contrastive_loss(p, t, num_segments, temperature)}
+    if with_grads:
+        B = p.shape[0]
+        seg = B // num_segments
+        dp = np.zeros_like(p)
+        for s in range(num_segments):
+            labels = np.arange(s * seg, (s + 1) * seg)
+            _, g, _ = infonce_segmented(p[s * seg:(s + 1) * seg], t, labels, temperature, return_grad=True)
+            dp[s * seg:(s + 1) * seg] = g / F32(num_segments)
+        dpooled = l2_normalize_backward(keep["pooled"], dp)
+        dad = readout_backward(keep["adapter_out"], keep["rmask"], readout, dpooled)
+        out["grads"] = adapter_backward(W, keep, dad, prec, prefix="adapter.")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer tail  (REF scripts/train_contrast.py:453-465,621-626: clip_grad_norm_ then AdamW)
+# ---------------------------------------------------------------------------------------------
+def clip_and_adamw(params, grads, m, v, step, lr=2e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                   max_norm=float("inf")):
+    """torch.nn.utils.clip_grad_norm_ (total L2 norm, coef = max_norm/(norm+1e-6) clamped to 1)
+    followed by torch.optim.AdamW (decoupled decay, bias correction).  In place; returns grad norm."""
+    tot = F32(math.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
+    coef = min(1.0, max_norm / (float(tot) + 1e-6)) if math.isfinite(max_norm) else 1.0
+    b1, b2 = betas
+    for k in params:
+        g = grads[k] * F32(coef)
+        params[k] *= F32(1.0 - lr * weight_decay)
+        m[k][...] = F32(b1) * m[k] + F32(1.0 - b1) * g
+        v[k][...] = F32(b2) * v[k] + F32(1.0 - b2) * g * g
+        bc1 = 1.0 - b1 ** step
+        bc2 = 1.0 - b2 ** step
+        denom = np.sqrt(v[k]) / F32(math.sqrt(bc2)) + F32(eps)
+        params[k] -= F32(lr / bc1) * (m[k] / denom)
+    return tot

@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (run in the build container only).
+
+The reference ships no tests or golden vectors, so parity is pinned on
+outputs of the reference's own Python for this path, imported from /root/reference exactly as
+SURVEY.md Appendix A describes: synthetic `models` / `dataset` / `scripts` packages (so the
+package __init__ files that need torch_geometric/graphein are not executed) plus name-only stubs
+for the absent third-party `esm` package that scripts/train_contrast.py imports but this path
+never calls.  What runs is the reference's code, verbatim:
+
+    models.modeling_esm2llama_instruct.Esm2LlamaInstructForCausalLM / ModalityAdapter
+    models.configuration_esm2llama_instruct.Esm2LlamaInstructConfig, models.modality_config
+    scripts.train_contrast.{readout_embeddings, get_description_embeddings, BatchInfoNCELoss,
+                            SegmentedBatchInfoNCELoss}
+
+on random-init towers built from local config objects (no from_pretrained, no network) whose
+weights come from the repo's counter-hash generator (p2t_hip.synth / p2t_hip.specs), so the
+fixtures hold only inputs' seeds and expected outputs -- never weights, never reference source.
+
+Usage (from /root/repo):  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only tiny,cfg1]
+This script and /root/reference never travel to the GPU box; only the .npz files do.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
+from p2t_hip import specs, synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def load_reference():
+    def _stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    _stub("esm").__path__ = []
+    _stub("esm.models").__path__ = []
+    _stub("esm.models.esmc", ESMC=type("ESMC", (), {}))
+    _stub("esm.utils", encoding=types.SimpleNamespace(tokenize_sequence=None)).__path__ = []
+    _stub("esm.utils.misc", stack_variable_length_tensors=None)
+    for p in ("models", "dataset", "scripts"):
+        _stub(p).__path__ = [f"{REF}/{p}"]
+    mm = importlib.import_module("models.modeling_esm2llama_instruct")
+    mc = importlib.import_module("models.modality_config")
+    cc = importlib.import_module("models.configuration_esm2llama_instruct")
+    ec = importlib.import_module("models.esmc_config")
+    eq = importlib.import_module("models.esmc_qwen_arc")
+    sys.modules["models"].__dict__.update(ModalityAdapter=mm.ModalityAdapter,
+                                          ModalityAdapterConfig=mc.ModalityAdapterConfig,
+                                          ESMCConfig=ec.ESMCConfig, ESMCQwen=eq.ESMCQwen)
+    dl = importlib.import_module("dataset.dataloader_light")
+    sys.modules["dataset"].__dict__.update(Prot2TextLightDataset=dl.Prot2TextLightDataset,
+                                           Prot2TextLightCollater=dl.Prot2TextLightCollater)
+    tc = importlib.import_module("scripts.train_contrast")
+    return types.SimpleNamespace(mm=mm, mc=mc, cc=cc, tc=tc)
+
+
+def build_reference_model(ref, esm: specs.EsmSpec, llama: specs.LlamaSpec, ad: specs.AdapterSpec, seed=0):
+    from transformers import EsmConfig, LlamaConfig
+    from transformers.models.esm.modeling_esm import EsmModel
+    from transformers.models.llama import LlamaForCausalLM
+
+    ecfg = EsmConfig(vocab_size=esm.vocab_size, hidden_size=esm.hidden_size,
+                     num_hidden_layers=esm.num_hidden_layers, num_attention_heads=esm.num_attention_heads,
+                     intermediate_size=esm.intermediate_size, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0, max_position_embeddings=esm.max_position_embeddings,
+                     layer_norm_eps=esm.layer_norm_eps, position_embedding_type="rotary",
+                     token_dropout=esm.token_dropout, emb_layer_norm_before=esm.emb_layer_norm_before,
+                     pad_token_id=esm.pad_token_id, mask_token_id=esm.mask_token_id)
+    ecfg._attn_implementation = "eager"
+    rope = {"rope_type": llama.rope_type, "rope_theta": llama.rope_theta}
+    if llama.rope_type == "llama3":
+        rope.update(factor=llama.rope_factor, low_freq_factor=llama.rope_low_freq_factor,
+                    high_freq_factor=llama.rope_high_freq_factor,
+                    original_max_position_embeddings=llama.rope_original_max_position_embeddings)
+    lcfg = LlamaConfig(vocab_size=llama.vocab_size, hidden_size=llama.hidden_size,
+                       intermediate_size=llama.intermediate_size, num_hidden_layers=llama.num_hidden_layers,
+                       num_attention_heads=llama.num_attention_heads,
+                       num_key_value_heads=llama.num_key_value_heads, rms_norm_eps=llama.rms_norm_eps,
+                       max_position_embeddings=llama.max_position_embeddings, rope_parameters=rope,
+                       tie_word_embeddings=llama.tie_word_embeddings, attention_bias=False, mlp_bias=False,
+                       attention_dropout=0.0, pad_token_id=None, bos_token_id=None, eos_token_id=None)
+    lcfg._attn_implementation = "eager"
+    with torch.device("cpu"):
+        esm_m = EsmModel(ecfg, add_pooling_layer=False)
+        llama_m = LlamaForCausalLM(lcfg)
+        acfg = ref.mc.ModalityAdapterConfig(input_dim=ad.input_dim, intermediate_dim=ad.intermediate_dim,
+                                            output_dim=ad.output_dim, dropout_rate=ad.dropout_rate)
+        adapter = ref.mm.ModalityAdapter(acfg)
+    model = ref.mm.Esm2LlamaInstructForCausalLM(esm_encoder=esm_m, adapter=adapter, llama_decoder=llama_m)
+
+    def load(module, tensors, allowed_missing):
+        sd = {k: torch.from_numpy(v) for k, v in specs.materialize(tensors, seed).items()}
+        res = module.load_state_dict(sd, strict=False)
+        bad = [k for k in res.missing_keys if not any(a in k for a in allowed_missing)]
+        assert not bad and not res.unexpected_keys, (bad, res.unexpected_keys)
+
+    load(model, specs.esm_tensors(esm, "esm_encoder."), ["adapter.", "llama_decoder.", "inv_freq", "contact_head"])
+    load(model, specs.adapter_tensors(ad, "adapter."), ["esm_encoder.", "llama_decoder."])
+    load(model, specs.llama_tensors(llama, "llama_decoder."), ["esm_encoder.", "adapter.", "lm_head", "inv_freq"])
+    model.eval()
+    model.requires_grad_(False)
+    return model
+
+
+def run_case(ref, name, esm, llama, ad, B, T_p, T_t, p_lens, t_lens, layers, id_high, pad_id, eos_id,
+             store_hidden=True, grads=True, seed_w=0, seed_in=1234):
+    tc = ref.tc
+    model = build_reference_model(ref, esm, llama, ad, seed_w)
+    pid, pmask = synth.protein_batch(seed_in, B, T_p, p_lens)
+    tid, tmask = synth.text_batch(seed_in, B, T_t, id_high, t_lens, pad_id, eos_id)
+    pid_t, pmask_t = torch.from_numpy(pid), torch.from_numpy(pmask)
+    tid_t, tmask_t = torch.from_numpy(tid), torch.from_numpy(tmask)
+    out = {}
+    F = torch.nn.functional
+    with torch.no_grad():
+        enc = model(protein_input_ids=pid_t, protein_attention_mask=pmask_t, return_encoder_outputs=True)[0]
+        ad_out, ad_mask = model(protein_input_ids=pid_t, protein_attention_mask=pmask_t,
+                                return_adapter_outputs=True)
+        assert torch.equal(ad_mask, pmask_t)
+        shim = types.SimpleNamespace(llm_decoder=model.llama_decoder)
+        ones = torch.ones_like(pmask_t)
+        for ro in ("last", "mean", "std", "mix"):
+            out[f"prot_pooled_{ro}"] = tc.readout_embeddings(ad_out, pmask_t, ro).numpy()
+        out["prot_pooled_mix_onesmask"] = tc.readout_embeddings(ad_out, ones, "mix").numpy()
+        p_mix = F.normalize(tc.readout_embeddings(ad_out, pmask_t, "mix"), p=2, dim=-1)
+        p_mix_ones = F.normalize(tc.readout_embeddings(ad_out, ones, "mix"), p=2, dim=-1)
+        p_mean = F.normalize(tc.readout_embeddings(ad_out, pmask_t, "mean"), p=2, dim=-1)
+        out["prot_norm_mix"], out["prot_norm_mix_onesmask"] = p_mix.numpy(), p_mix_ones.numpy()
+        out["prot_norm_mean"] = p_mean.numpy()
+        hs_all = model.llama_decoder.model(input_ids=tid_t, attention_mask=tmask_t, use_cache=False,
+                                           output_attentions=False, output_hidden_states=True,
+                                           return_dict=True).hidden_states
+        assert len(hs_all) == llama.num_hidden_layers + 1
+        for k in layers:
+            # the reference's own text-side function, verbatim (readout "mix")
+            d = tc.get_description_embeddings(shim, tid_t, tmask_t, output_llm_layer=k)
+            out[f"text_pooled_mix_L{k}"] = d.numpy()
+            t_mix = F.normalize(d, p=2, dim=-1)
+            out[f"text_norm_mix_L{k}"] = t_mix.numpy()
+            t_mean = F.normalize(tc.readout_embeddings(hs_all[k], tmask_t, "mean"), p=2, dim=-1)
+            out[f"text_norm_mean_L{k}"] = t_mean.numpy()
+            if store_hidden:
+                out[f"text_hidden_L{k}"] = hs_all[k].numpy()
+            labels_all = torch.arange(B)
+            out[f"loss_batch_mix_L{k}"] = tc.BatchInfoNCELoss()(p_mix, t_mix).numpy()
+            out[f"loss_batch_mix_onesmask_L{k}"] = tc.BatchInfoNCELoss()(p_mix_ones, t_mix).numpy()
+            out[f"loss_batch_mean_L{k}"] = tc.BatchInfoNCELoss()(p_mean, t_mean).numpy()
+            for nseg in (1, 2):
+                seg = B // nseg
+                acc = torch.zeros([])
+                for s in range(nseg):
+                    acc += tc.SegmentedBatchInfoNCELoss()(p_mix[s * seg:(s + 1) * seg], t_mix,
+                                                          labels_all[s * seg:(s + 1) * seg])
+                out[f"loss_seg{nseg}_mix_L{k}"] = (acc / nseg).numpy()
+            out[f"logits_mix_L{k}"] = (p_mix @ t_mix.t() / 0.05).numpy()
+        if store_hidden:
+            out["esm_last_hidden"] = enc.numpy()
+            out["adapter_out"] = ad_out.numpy()
+        else:   # strided sample keeps the fixture small
+            out["esm_last_hidden_s"] = enc[:, ::7, ::5].contiguous().numpy()
+            out["adapter_out_s"] = ad_out[:, ::7, ::13].contiguous().numpy()
+    if grads:
+        # adapter gradients through the reference loss: train-mode forward with dropout_rate = 0
+        k = layers[-1]
+        model.adapter.requires_grad_(True)
+        model.adapter.dropout.p = 0.0
+        model.adapter.train()
+        ad_out, _ = model(protein_input_ids=pid_t, protein_attention_mask=pmask_t, return_adapter_outputs=True)
+        t_mix = torch.from_numpy(out[f"text_norm_mix_L{k}"])
+        for nseg in (1, 2):
+            model.adapter.zero_grad()
+            p_mix = F.normalize(tc.readout_embeddings(ad_out, pmask_t, "mix"), p=2, dim=-1)
+            seg = B // nseg
+            acc = torch.zeros([])
+            for s in range(nseg):
+                acc = acc + tc.SegmentedBatchInfoNCELoss()(p_mix[s * seg:(s + 1) * seg], t_mix,
+                                                           torch.arange(s * seg, (s + 1) * seg))
+            (acc / nseg).backward(retain_graph=True)
+            for n, prm in model.adapter.named_parameters():
+                if prm.grad is not None:
+                    out[f"grad_seg{nseg}_{n}"] = prm.grad.numpy().copy()
+                else:
+                    assert n.startswith("ln"), n      # ln1/ln2 are unused
+        # one clip + AdamW step with the reference's optimizer settings (train_contrast.py:621-626)
+        model.adapter.zero_grad()
+        p_mix = F.normalize(tc.readout_embeddings(ad_out, pmask_t, "mix"), p=2, dim=-1)
+        loss = tc.SegmentedBatchInfoNCELoss()(p_mix, t_mix, torch.arange(B))
+        loss.backward()
+        opt = torch.optim.AdamW(model.adapter.parameters(), lr=2e-4, eps=1e-6, betas=(0.9, 0.999))
+        gn = torch.nn.utils.clip_grad_norm_(model.adapter.parameters(), max_norm=0.05)
+        opt.step()
+        out["opt_gradnorm"] = gn.numpy()
+        for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+            out[f"opt_after_{n}"] = dict(model.adapter.named_parameters())[n].detach().numpy().copy()
+    meta = dict(name=name, B=B, T_p=T_p, T_t=T_t, p_lens=list(p_lens), t_lens=list(t_lens), layers=list(layers),
+                id_high=id_high, pad_id=pad_id, eos_id=eos_id, seed_w=seed_w, seed_in=seed_in,
+                esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad))
+    import json
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, {len(out)} arrays")
+
+
+def run_ops(ref):
+    """Function-level known answers from the reference's own readout / loss code on random input."""
+    tc = ref.tc
+    out = {}
+    B, T, D = 5, 11, 24
+    emb = synth.uniform_f32(7, "ops.emb", (B, T, D), 2.0, 0.3)
+    lens = [11, 8, 5, 2, 1]
+    mask = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    out["emb"], out["mask"] = emb, mask
+    for ro in ("last", "mean", "std", "mix"):
+        out[f"readout_{ro}"] = tc.readout_embeddings(torch.from_numpy(emb), torch.from_numpy(mask), ro).numpy()
+    p = torch.nn.functional.normalize(torch.from_numpy(synth.uniform_f32(7, "ops.p", (6, 32), 1.0)), dim=-1)
+    t = torch.nn.functional.normalize(torch.from_numpy(synth.uniform_f32(7, "ops.t", (6, 32), 1.0)), dim=-1)
+    out["p"], out["t"] = p.numpy(), t.numpy()
+    out["loss_batch"] = tc.BatchInfoNCELoss()(p, t).numpy()
+    out["loss_batch_t01"] = tc.BatchInfoNCELoss(temperature=0.1)(p, t).numpy()
+    labels = torch.tensor([3, 4, 5])
+    out["loss_seg"] = tc.SegmentedBatchInfoNCELoss()(p[3:6], t, labels).numpy()
+    path = os.path.join(HERE, "ops.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,cfg1")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    if "ops" in only:
+        run_ops(ref)
+    if "tiny" in only:
+        esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+        llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,
+                                num_key_value_heads=2, vocab_size=512)
+        ad = specs.AdapterSpec(64, 96, 64, 0.3)
+        run_case(ref, "tiny", esm, llama, ad, B=4, T_p=24, T_t=12, p_lens=[24, 15, 7, 3], t_lens=[12, 9, 5, 2],
+                 layers=[2, 3], id_high=500, pad_id=510, eos_id=509)
+    if "tiny_d24" in only:
+        esm = specs.EsmSpec(num_hidden_layers=3, hidden_size=96, intermediate_size=192, num_attention_heads=4)
+        llama = specs.LlamaSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=256, num_attention_heads=4,
+                                num_key_value_heads=1, vocab_size=300, rope_type="default", rope_theta=10000.0)
+        ad = specs.AdapterSpec(96, 80, 128, 0.3)
+        run_case(ref, "tiny_d24", esm, llama, ad, B=6, T_p=40, T_t=20, p_lens=[40, 33, 21, 10, 4, 2],
+                 t_lens=[20, 20, 13, 7, 3, 1], layers=[1, 2], id_high=290, pad_id=299, eos_id=298)
+    if "cfg1" in only:
+        name_e, name_l, _, B, T_p, T_t = specs.CONFIGS["cfg1"]
+        esm, llama = specs.esm_spec(name_e), specs.llama_spec(name_l)
+        ad = specs.adapter_spec(esm, llama)
+        run_case(ref, "cfg1", esm, llama, ad, B=B, T_p=T_p, T_t=T_t, p_lens=[128, 77, 32, 5], t_lens=[64, 40, 17, 3],
+                 layers=[16], id_high=128000, pad_id=128002, eos_id=128009, store_hidden=False, grads=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""CPU: the numpy oracle (oracle/p2t_oracle.py) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  Tolerances are fp32 round-off: both sides are fp32 CPU."""
+import numpy as np
+import pytest
+
+from oracle import p2t_oracle as O
+from helpers import case_setup, model_weights, rel_err
+
+TOL = 2e-5     # relative L2, fp32 vs fp32 with different summation orders
+
+
+def test_ops_readout_and_losses(golden):
+    g = golden("ops")
+    for ro in ("last", "mean", "std", "mix"):
+        np.testing.assert_allclose(O.readout_embeddings(g["emb"], g["mask"], ro), g[f"readout_{ro}"],
+                                   rtol=2e-5, atol=2e-6)
+    assert abs(O.infonce_batch(g["p"], g["t"]) - g["loss_batch"]) < 1e-5
+    assert abs(O.infonce_batch(g["p"], g["t"], 0.1) - g["loss_batch_t01"]) < 1e-5
+    assert abs(O.infonce_segmented(g["p"][3:6], g["t"], np.array([3, 4, 5])) - g["loss_seg"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24"])
+def test_towers_and_step(golden, case):
+    g = golden(case)
+    meta = g["meta"]
+    esm, llama, ad, pid, pmask, tid, tmask = case_setup(meta)
+    W = model_weights(esm, llama, ad, meta["seed_w"])
+    enc = O.esm2_forward(esm, W, pid, pmask, prefix="esm_encoder.")
+    assert rel_err(enc, g["esm_last_hidden"]) < TOL
+    keep = {}
+    ad_out = O.adapter_forward(W, enc, prefix="adapter.", keep=keep)
+    assert rel_err(ad_out, g["adapter_out"]) < TOL
+    for ro in ("last", "mean", "std", "mix"):
+        assert rel_err(O.readout_embeddings(ad_out, pmask, ro), g[f"prot_pooled_{ro}"]) < TOL
+    assert rel_err(O.readout_embeddings(ad_out, np.ones_like(pmask), "mix"), g["prot_pooled_mix_onesmask"]) < TOL
+    for k in meta["layers"]:
+        hs = O.llama_hidden_state(llama, W, tid, tmask, k, prefix="llama_decoder.")
+        assert rel_err(hs, g[f"text_hidden_L{k}"]) < TOL
+        t = O.text_embeddings(llama, W, tid, tmask, k, "mix")
+        assert rel_err(t, g[f"text_norm_mix_L{k}"]) < TOL
+        p = O.protein_embeddings(esm, W, pid, pmask, "mix")
+        assert rel_err(p, g["prot_norm_mix"]) < TOL
+        assert rel_err(p @ t.T / 0.05, g[f"logits_mix_L{k}"]) < TOL
+        for nseg in (1, 2):
+            assert abs(O.contrastive_loss(p, t, nseg) - g[f"loss_seg{nseg}_mix_L{k}"]) < 2e-5
+        assert abs(O.infonce_batch(p, t) - g[f"loss_batch_mix_L{k}"]) < 2e-5
+        p1 = O.protein_embeddings(esm, W, pid, pmask, "mix", ones_mask=True)
+        assert abs(O.infonce_batch(p1, t) - g[f"loss_batch_mix_onesmask_L{k}"]) < 2e-5
+        pm = O.protein_embeddings(esm, W, pid, pmask, "mean")
+        tm = O.text_embeddings(llama, W, tid, tmask, k, "mean")
+        assert abs(O.infonce_batch(pm, tm) - g[f"loss_batch_mean_L{k}"]) < 2e-5
+    # adapter gradients through readout / normalise / loss (reference autograd)
+    k = meta["layers"][-1]
+    for nseg in (1, 2):
+        out = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=k, num_segments=nseg, with_grads=True)
+        for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+            assert rel_err(out["grads"]["adapter." + n], g[f"grad_seg{nseg}_{n}"]) < 1e-4, n
+
+
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24"])
+def test_clip_adamw_step(golden, case):
+    g = golden(case)
+    meta = g["meta"]
+    esm, llama, ad, pid, pmask, tid, tmask = case_setup(meta)
+    W = model_weights(esm, llama, ad, meta["seed_w"])
+    out = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=meta["layers"][-1], with_grads=True)
+    names = ["adapter." + n for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")]
+    params = {n: W[n].copy() for n in names}
+    m = {n: np.zeros_like(params[n]) for n in names}
+    v = {n: np.zeros_like(params[n]) for n in names}
+    gn = O.clip_and_adamw(params, out["grads"], m, v, step=1, max_norm=0.05)
+    assert abs(gn - g["opt_gradnorm"]) < 1e-4 * max(1.0, float(g["opt_gradnorm"]))
+    for n in names:
+        np.testing.assert_allclose(params[n], g["opt_after_" + n[len("adapter."):]], rtol=1e-5, atol=2e-7)
