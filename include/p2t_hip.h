@@ -1,0 +1,236 @@
+/* libp2t_hip -- C ABI of the MI355X-native contrastive-alignment hot path of Prot2Text-V2.
+ *
+ * The reference (RockingMat/Prot2Text-V2-esm3) is pure Python: it has no FFI, the hot path is
+ * reached through nn.Module calls.  This header is the drop-in boundary a maintainer binds with
+ * ctypes (INTEGRATION.md shows the stub); every entry point names the reference call it replaces:
+ *
+ *   p2t_esm2_forward          Esm2LlamaInstructForCausalLM.forward(return_encoder_outputs=True)
+ *                             models/modeling_esm2llama_instruct.py:175-189 -> HF EsmModel.forward
+ *   p2t_adapter_forward       ModalityAdapter.forward, models/modeling_esm2llama_instruct.py:60-68
+ *   p2t_adapter_backward      autograd of the same (loss.backward(), scripts/train_contrast.py:448)
+ *   p2t_llama_hidden_forward  llm_decoder.model(..., output_hidden_states=True).hidden_states[k]
+ *                             scripts/train_contrast.py:292-304 -> HF LlamaModel.forward
+ *   p2t_readout / _backward   readout_embeddings, scripts/train_contrast.py:198-248
+ *   p2t_l2norm_rows           torch.nn.functional.normalize(p=2, dim=-1), train_contrast.py:354,365
+ *   p2t_infonce_forward/_backward  SegmentedBatchInfoNCELoss / BatchInfoNCELoss, train_contrast.py:72-114
+ *   p2t_clip_adamw_step       clip_grad_norm_ + AdamW.step, train_contrast.py:453-465,621-626
+ *
+ * Conventions: plain pointers and sizes, no framework types.  All pointers are DEVICE pointers
+ * unless named host_*.  Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*),
+ * never allocates, never synchronises; buffers are owned by the caller (PyTorch's allocator in the
+ * Python host).  Return value: P2T_OK or a negative code, text via p2t_last_error().
+ * The library is re-entrant per stream; the only global state is the thread-local error string.
+ */
+#ifndef P2T_HIP_H
+#define P2T_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2T_VERSION 100
+
+enum { P2T_OK = 0, P2T_ERR_ARG = -1, P2T_ERR_HIP = -2, P2T_ERR_UNSUPPORTED = -3 };
+enum { P2T_F32 = 0, P2T_BF16 = 1 };                       /* storage dtype of weights / activations */
+enum { P2T_READOUT_LAST = 0, P2T_READOUT_MEAN = 1, P2T_READOUT_STD = 2, P2T_READOUT_MIX = 3 };
+enum {                                                     /* GEMM epilogues (p2t_gemm_nt) */
+    P2T_EPI_STORE = 0,      /* C = acc + bias                                   */
+    P2T_EPI_GELU = 1,       /* C = gelu_erf(acc + bias); optional Z = acc + bias */
+    P2T_EPI_RESID = 2,      /* R(f32, in place) += acc + bias                   */
+    P2T_EPI_SWIGLU = 3,     /* C[m, f] = silu(gate) * up, gate/up interleaved by 16 rows of W */
+    P2T_EPI_STORE_F32 = 4,  /* C(f32) = acc (+ C if accumulate)                  */
+    P2T_EPI_GELU_BWD = 5    /* C = acc * gelu_erf'(Z), Z read from z (adapter backward) */
+};
+
+typedef void* p2t_stream;
+
+int p2t_version(void);
+const char* p2t_last_error(void);
+/* sizeof() of the ABI structs, for bindings to self-check: 0 esm2_config, 1 esm2_layer, 2 esm2_weights,
+ * 3 llama_config, 4 llama_layer, 5 llama_weights, 6 adapter_config, 7 adapter_weights, 8 adapter_saved. */
+size_t p2t_struct_size(int which);
+
+/* ---------------------------------------------------------------- synthetic data (bench / tests) */
+/* dst[i] = (int(hash24(i)) - 2^23) * scale23 + offset ; see p2t_hip/synth.py (bit-identical). */
+int p2t_fill_hash(void* dst, int64_t n, uint64_t add, uint64_t xorv, float scale23, float offset,
+                  int dtype, p2t_stream stream);
+int p2t_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, p2t_stream stream);
+/* x[i] *= scalar[0], scalar on the device (chain-rule scaling of a gradient without a host sync). */
+int p2t_scale_by_device_scalar(float* x, int64_t n, const float* scalar, p2t_stream stream);
+/* dst[c, r] = src[r, c]  (row strides in elements) */
+int p2t_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, void* dst, int64_t ld_dst,
+                  int dtype, p2t_stream stream);
+
+/* ---------------------------------------------------------------- building blocks */
+/* C[M,N] = A[M,K] * W[N,K]^T with a fused epilogue.  A, W: `dtype`, K-contiguous, row strides
+ * lda/ldw (elements, multiples of 8).  For dtype BF16 with K % 64 == 0 the MFMA kernel runs
+ * (v_mfma_f32_16x16x32_bf16, 256x256x64 LDS tiles); otherwise the fp32-FMA kernel.  bias: f32 [N] or NULL.
+ * out: `out_dtype` [M, ldc]; columns N..min(ldc, N rounded up to 64)-1 are written as zeros (they are the zero
+ * K-padding of the next GEMM).  z (GELU only, may be NULL): pre-activation, out_dtype, same stride.  EPI_RESID: out is f32 and accumulated in place.  EPI_SWIGLU: N is the
+ * interleaved gate/up row count, out has N/2 columns.  use_mfma: -1 auto, 0 force FMA kernel, 1 require MFMA. */
+int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
+                void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
+                int use_mfma, p2t_stream stream);
+
+/* torch.nn.LayerNorm over the last dim: x f32 [rows, ld_x] -> y `out_dtype` [rows, ld_y]; pad zeroed. */
+int p2t_layernorm(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* y, int64_t ld_y,
+                  int64_t rows, int64_t cols, int out_dtype, p2t_stream stream);
+/* LlamaRMSNorm (fp32 variance, weight last). */
+int p2t_rmsnorm(const float* x, int64_t ld_x, const float* w, float eps, void* y, int64_t ld_y, int64_t rows,
+                int64_t cols, int out_dtype, p2t_stream stream);
+
+/* mask int64 [B, T] -> key_mask u8 [B, T]; kv_info i32 [2B]: [b] = 1 + last valid key, [B + b] = 1 if the mask
+ * is a plain prefix (the right-padded batch contract); emb_scale f32 [2B] (optional, ESM token-dropout rescale:
+ * numerator, denominator; needs ids). */
+int p2t_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
+                     uint8_t* key_mask, int32_t* kv_info, float* emb_scale, p2t_stream stream);
+/* Head split + query scale + rotary + V transpose.  qkv `dtype` [B*T, ldq] rows = [q heads | k heads | v heads];
+ * inv_freq f32 [d/2]; cos_sin_scratch f32 [T * d].  Outputs as p2t_attention expects them. */
+int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos_sin_scratch, void* q, void* k,
+                 void* vt, int B, int T, int nh, int nkv, int d, int dp, int tp, float q_scale, int dtype,
+                 p2t_stream stream);
+
+/* Attention.  q [B, nh, T, dp], k [B, nkv, T, dp], vt [B, nkv, dp, tp] (V transposed, tp = T rounded up
+ * to 64), all `dtype`; head dim padded with zeros to dp in {32, 64, 128}.  key_mask u8 [B, T] (1 = valid),
+ * kv_info i32 [2B] from p2t_mask_prepare.  softmax(scale * q k^T + mask) v -> out [B*T, ld_out] `dtype`,
+ * head h in columns h*d..h*d+d-1; columns nh*d..ld_out-1 zeroed.  causal: also require key <= query. */
+int p2t_attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info,
+                  void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale,
+                  int causal, int dtype, int use_mfma, p2t_stream stream);
+
+/* ---------------------------------------------------------------- ESM2 encoder */
+typedef struct {
+    int32_t n_layers, hidden, ffn, heads, head_dim, vocab;
+    int32_t pad_id, mask_id, token_dropout, emb_layer_norm_before;
+    float layer_norm_eps, rope_theta;
+    int32_t dtype;                       /* P2T_F32 | P2T_BF16 */
+} p2t_esm2_config;
+
+/* Packed per-layer weights (device).  Matrices are `dtype`, row-major [N][ld], ld = K rounded up
+ * to 64, zero padded.  qkv_w rows: query (H), key (H), value (H).  Vectors are f32. */
+typedef struct {
+    const void* qkv_w;  const float* qkv_b;
+    const void* o_w;    const float* o_b;
+    const float* ln1_w; const float* ln1_b;          /* attention.LayerNorm */
+    const void* fc1_w;  const float* fc1_b;          /* intermediate.dense  */
+    const void* fc2_w;  const float* fc2_b;          /* output.dense        */
+    const float* ln2_w; const float* ln2_b;          /* layer LayerNorm     */
+} p2t_esm2_layer;
+
+typedef struct {
+    const void* word_emb;                            /* [vocab][hidden] dtype, unpadded */
+    const float* emb_ln_w; const float* emb_ln_b;    /* only if emb_layer_norm_before */
+    const p2t_esm2_layer* layers;                    /* HOST array of n_layers structs */
+    const float* final_ln_w; const float* final_ln_b;
+    const float* inv_freq;                           /* rotary_embeddings.inv_freq f32 [head_dim/2] (a checkpoint
+                                                        buffer in HF); NULL = 1/theta^(2j/d) computed on device */
+} p2t_esm2_weights;
+
+size_t p2t_esm2_workspace_bytes(const p2t_esm2_config* cfg, int B, int T);
+/* ids, mask: int64 [B, T] (right-padded batch contract, dataset/dataloader.py:113-123).
+ * out: last_hidden_state, `dtype` [B*T, ld_out] (ld_out >= hidden; pad columns zeroed). */
+int p2t_esm2_forward(const p2t_esm2_config* cfg, const p2t_esm2_weights* w, const int64_t* ids,
+                     const int64_t* mask, int B, int T, void* out, int64_t ld_out, void* workspace,
+                     size_t workspace_bytes, p2t_stream stream);
+
+/* ---------------------------------------------------------------- Llama text tower */
+typedef struct {
+    int32_t n_layers, hidden, ffn, heads, kv_heads, head_dim, vocab;
+    float rms_norm_eps, rope_theta;
+    int32_t rope_llama3;                 /* 0 default, 1 llama3 scaling */
+    float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+    int32_t rope_original_max_pos;
+    int32_t dtype;
+} p2t_llama_config;
+
+/* qkv_w rows: q (heads*d), k (kv*d), v (kv*d).  gu_w: gate/up interleaved in blocks of 16 rows
+ * (rows 32j..32j+15 = gate 16j.., rows 32j+16..32j+31 = up 16j..).  No biases. */
+typedef struct {
+    const void* qkv_w; const void* o_w; const void* gu_w; const void* down_w;
+    const float* ln1_w;                              /* input_layernorm */
+    const float* ln2_w;                              /* post_attention_layernorm */
+} p2t_llama_layer;
+
+typedef struct {
+    const void* embed;                               /* [vocab][hidden] dtype */
+    const p2t_llama_layer* layers;                   /* HOST array, at least the first k layers */
+    const float* final_norm_w;
+    const float* inv_freq;                           /* f32 [head_dim/2] or NULL = computed from the config */
+} p2t_llama_weights;
+
+size_t p2t_llama_workspace_bytes(const p2t_llama_config* cfg, int B, int T);
+/* hidden_states[k]: residual stream after k layers (k < n_layers) or the post-norm output (k == n_layers).
+ * out: f32 [B*T, hidden]. */
+int p2t_llama_hidden_forward(const p2t_llama_config* cfg, const p2t_llama_weights* w, const int64_t* ids,
+                             const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                             size_t workspace_bytes, p2t_stream stream);
+
+/* ---------------------------------------------------------------- ModalityAdapter */
+typedef struct {
+    int32_t input_dim, intermediate_dim, output_dim;
+    float dropout_p;                     /* 0 in eval */
+    uint64_t dropout_seed;
+    int32_t dtype;
+} p2t_adapter_config;
+
+typedef struct {                          /* matrices `dtype` [N][ld = K up to 64]; biases f32 */
+    const void* fc1_w; const float* fc1_b; const void* fc2_w; const float* fc2_b;
+} p2t_adapter_weights;
+
+/* Activation buffers (caller-allocated, M = rows): z1,h1 [M, ld(intermediate)], z2,g2 [M, ld(output)] `dtype`,
+ * ld(n) = n rounded up to 64; inv_norm f32 [M].  h1 and g2 are always required (they are the forward's
+ * intermediates); z1, z2, inv_norm may be NULL for inference and are required by p2t_adapter_backward. */
+typedef struct { void* z1; void* h1; void* z2; void* g2; float* inv_norm; } p2t_adapter_saved;
+
+/* x `dtype` [M, ld_x] -> y `dtype` [M, ld(output_dim)], rows L2-normalised. */
+int p2t_adapter_forward(const p2t_adapter_config* cfg, const p2t_adapter_weights* w, const void* x, int64_t ld_x,
+                        int64_t M, void* y, const p2t_adapter_saved* save, p2t_stream stream);
+size_t p2t_adapter_backward_workspace_bytes(const p2t_adapter_config* cfg, int64_t M);
+/* dy f32 [M, output_dim] -> f32 gradients (accumulated if accumulate != 0): d_fc1_w [I, input_dim],
+ * d_fc1_b [I], d_fc2_w [O, I], d_fc2_b [O] (unpadded, contiguous). */
+int p2t_adapter_backward(const p2t_adapter_config* cfg, const p2t_adapter_weights* w, const void* x, int64_t ld_x,
+                         int64_t M, const p2t_adapter_saved* saved, const float* dy, float* d_fc1_w, float* d_fc1_b,
+                         float* d_fc2_w, float* d_fc2_b, int accumulate, void* workspace, size_t workspace_bytes,
+                         p2t_stream stream);
+
+/* ---------------------------------------------------------------- readout / normalise / loss */
+/* emb [B, T, ld] (`dtype`, or f32), mask int64 [B, T] (NULL = all ones) -> out f32 [B, D] (mean/std/last)
+ * or [B, 2D] (mix). */
+int p2t_readout(const void* emb, int dtype, int64_t ld, const int64_t* mask, int B, int T, int D, int mode,
+                float* out, p2t_stream stream);
+/* d_out f32 [B, D or 2D] -> d_emb f32 [B, T, D]. */
+int p2t_readout_backward(const void* emb, int dtype, int64_t ld, const int64_t* mask, int B, int T, int D, int mode,
+                         const float* pooled, const float* d_out, float* d_emb, p2t_stream stream);
+/* y = x / max(||x||, eps) per row; inv_norm (optional) f32 [rows]. */
+int p2t_l2norm_rows(const float* x, float* y, float* inv_norm, int64_t rows, int64_t cols, float eps,
+                    p2t_stream stream);
+int p2t_l2norm_rows_backward(const float* x, const float* dy, float* dx, int64_t rows, int64_t cols, float eps,
+                             p2t_stream stream);
+/* Row-wise InfoNCE of `seg` [S, D] against `batch` [N, D] (both f32, L2-normalised), labels i32 [S]:
+ * loss_out[0] (+)= weight * mean_i( logsumexp_j(l_ij) - l_i,label_i ), l = seg batch^T / temperature.
+ * logits f32 [S, N] and row_loss f32 [S] are outputs / scratch (required). */
+int p2t_infonce_forward(const float* seg, const float* batch, const int32_t* labels, int S, int N, int D,
+                        float temperature, float weight, int accumulate, float* loss_out, float* logits,
+                        float* row_loss, p2t_stream stream);
+/* d_seg f32 [S, D] = weight * d loss / d seg, from the logits the forward wrote. */
+int p2t_infonce_backward(const float* batch, const int32_t* labels, const float* logits, int S, int N, int D,
+                         float temperature, float weight, float* d_seg, p2t_stream stream);
+
+/* ---------------------------------------------------------------- optimizer tail */
+/* One clip_grad_norm_(max_norm) + AdamW step over n_tensors (<= 64) f32 parameter tensors (HOST arrays of
+ * device pointers).  shadow[i] (optional, may be NULL per tensor) receives the updated parameter in
+ * `shadow_dtype` as a matrix with cols[i] columns and row stride shadow_ld[i] (the GEMM-layout copy the
+ * next forward reads).  max_norm <= 0 or >= 1e30 = no clipping.  grad_norm_out f32 [1] (device): total norm
+ * before clipping.  scratch: f32 [256 * n_tensors]. */
+int p2t_clip_adamw_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, void* const* shadow, const int64_t* cols,
+                        const int64_t* shadow_ld, int shadow_dtype, int step, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, double max_norm, float* grad_norm_out, float* scratch,
+                        p2t_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2T_HIP_H */

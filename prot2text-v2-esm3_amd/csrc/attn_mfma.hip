@@ -1,0 +1,229 @@
+// bf16 flash attention forward for gfx950 (ESM2 bidirectional + key padding, Llama causal GQA).
+//
+// One workgroup = 4 wavefronts = 128 queries of one (batch, head); each wave owns 32 queries.
+// Per 64-key step:   S^T = K . Q^T   (v_mfma_f32_32x32x16_bf16, keys on the accumulator rows, the
+// query on the lane, so the softmax row statistics are lane-local + one lane^32 exchange), then
+// O^T += V^T . P^T with the S^T accumulators converted in place to the B operand (no LDS round trip:
+// "accumulator tile as the next MFMA's operand", cdna_hip_programming.md section 3).  The K rows are
+// loaded in the order that makes the matching V^T operand 8 CONTIGUOUS keys: row i of the K
+// fragment holds key pi(i), pi = swap bits 2 and 3 -- a pure address permutation.
+// V arrives already transposed ([dp][tp], written by the QKV post-pass), so both operands are
+// plain 16-byte row reads.  K / V^T tiles are staged with global_load_lds (double buffered), the
+// bank swizzle applied on the source address and on the ds_read (rule 21):
+//   rows of RB bytes, chunk c of row r stored at c ^ ((r / (256/RB)) & (RB/16 - 1))  -- conflict
+//   free for the 32-row fragment pattern of ds_read_b128.
+// Softmax in fp32 with exp2 (log2(e) folded into the scale); P is rounded to bf16 for the PV MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace p2t {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+__device__ __forceinline__ int perm23(int i) {       // swap bits 2 and 3
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+}
+
+template <int DP>
+__global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ vt, const uint8_t* __restrict__ key_mask,
+                                                        const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out,
+                                                        int64_t ld_out, int B, int seq, int nh, int nkv, int d, int tp,
+                                                        float scale_log2e, int causal, int out_cols) {
+    constexpr int RB = DP * 2;                 // K-tile row bytes
+    constexpr int CR = DP / 8;                 // 16-B chunks per K row
+    constexpr int RPB = 128 / DP;              // K rows per 256-B bank row (DP=128 -> 1 handled below)
+    constexpr int KT_BYTES = 64 * RB;          // K tile: 64 keys
+    constexpr int VT_BYTES = DP * 128;         // V^T tile: DP rows x 64 keys
+    constexpr int STAGE = KT_BYTES + VT_BYTES;
+    constexpr int NI = DP / 32;                // glds instructions per wave per tile
+    constexpr int DK = DP / 16;                // QK^T k-steps
+    constexpr int DT = DP / 32;                // O^T row tiles
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (nh / nkv);
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int lq = lane & 31, hh = lane >> 5;
+    const int query = q0 + lq;
+
+    int end = kv_info[b];
+    const int prefix = kv_info[B + b];
+    if (causal) end = min(end, (int)blockIdx.x * 128 + 128);
+    const int n_it = (end + 63) >> 6;
+
+    const bf16_t* kbase = k + ((int64_t)(b * nkv + hk) * seq) * DP;
+    const bf16_t* vbase = vt + ((int64_t)(b * nkv + hk) * DP) * tp;
+
+    // ---- Q fragments (B operand of K.Q^T): lane holds Q[query][kk*16 + 8*hh .. +8] ----
+    bf16x8 qf[DK];
+    {
+        const int qr = query < seq ? query : seq - 1;
+        const bf16_t* qrow = q + ((int64_t)(b * nh + h) * seq + qr) * DP + 8 * hh;
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+    }
+
+    // ---- staging (global_load_lds, 1 KiB per wave instruction) ----
+    auto f_k = [](int row) { return DP == 128 ? (row & 15) : ((row / (RPB > 0 ? RPB : 1)) & (CR - 1)); };
+    auto stage = [&](int buf, int it) {
+        const int kb = it * 64;
+        char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int ii = w + 4 * i;
+            const int byte = ii * 1024 + lane * 16;
+            const int row = byte / RB, p = (byte % RB) >> 4;
+            const int c = p ^ f_k(row);
+            int key = kb + row;
+            key = key < seq ? key : seq - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (int64_t)key * DP + c * 8), (lptr_t)(sb + ii * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int ii = w + 4 * i;
+            const int row = ii * 8 + (lane >> 3), p = lane & 7;
+            const int c = p ^ ((row >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vbase + (int64_t)row * tp + kb + c * 8),
+                                             (lptr_t)(sb + KT_BYTES + ii * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets ----
+    int k_off[2][DK];                          // [tile][k-step]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = t * 32 + perm23(lq);
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) k_off[t][kk] = row * RB + (((kk * 2 + hh) ^ f_k(row)) << 4);
+    }
+    int v_off[DT][4];                          // [d-tile][k-step over the 64 keys]
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int row = dt * 32 + lq;
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) v_off[dt][ss] = KT_BYTES + row * 128 + (((ss * 2 + hh) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    f32x16 ot[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (n_it > 0) stage(0, 0);
+    for (int it = 0; it < n_it; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < n_it) stage((it + 1) & 1, it + 1);
+        const char* sb = smem + (it & 1) * STAGE;
+        const int kb = it * 64;
+
+        // S^T tiles: rows = keys (permuted), cols = queries
+        f32x16 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off[t][kk]);
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[t], 0, 0, 0);
+            }
+        }
+        // mask + running max.  Register r of tile t is key kb + 32t + 16(r>>3) + 8hh + (r&7).
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + 32 * t + 16 * (r >> 3) + 8 * hh + (r & 7);
+                bool ok = key < end && (!causal || key <= query);
+                if (!prefix) ok = ok && key < seq && key_mask[(int64_t)b * seq + (key < seq ? key : 0)];
+                const float sv = ok ? st[t][r] * scale_log2e : -INFINITY;
+                st[t][r] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;       // fully masked so far: p = exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0
+        float lsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[t][r] - m_use);
+                st[t][r] = p;
+                lsum += p;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[ss >> 1][8 * (ss & 1) + j];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + v_off[dt][ss]);
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O^T rows = channels (r&3) + 8(r>>2) + 4hh, col = query ----
+    if (query < seq) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* orow = out + ((int64_t)b * seq + query) * ld_out + h * d;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c0 = dt * 32 + 8 * rg + 4 * hh;
+                if (c0 < d) {
+                    const float v[4] = {ot[dt][4 * rg] * inv, ot[dt][4 * rg + 1] * inv, ot[dt][4 * rg + 2] * inv,
+                                        ot[dt][4 * rg + 3] * inv};
+                    store4(orow + c0, v);
+                }
+            }
+        if (h == nh - 1)
+            for (int c = nh * d + 4 * hh; c < out_cols; c += 8) {
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                store4(out + ((int64_t)b * seq + query) * ld_out + c, z);
+            }
+    }
+}
+
+int launch_attn_mfma(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info,
+                     void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale,
+                     int causal, hipStream_t s) {
+    P2T_REQUIRE(d % 4 == 0 && (dp == 32 || dp == 64 || dp == 128) && d <= dp && nh % nkv == 0 && tp % 64 == 0 && tp >= T &&
+                    (nh * d) % 4 == 0 && ld_out % 4 == 0,
+                "attention(mfma): unsupported shape d=%d dp=%d tp=%d heads %d/%d", d, dp, tp, nh, nkv);
+    const dim3 grid((unsigned)ceil_div(T, 128), (unsigned)nh, (unsigned)B);
+    const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
+    const float sl = scale * 1.4426950408889634f;
+#define P2T_ATTN(DPV)                                                                                               \
+    attn_mfma_kernel<DPV><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, key_mask, kv_info, \
+                                               (bf16_t*)out, ld_out, B, T, nh, nkv, d, tp, sl, causal, out_cols)
+    if (dp == 32) P2T_ATTN(32);
+    else if (dp == 64) P2T_ATTN(64);
+    else P2T_ATTN(128);
+#undef P2T_ATTN
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+}  // namespace p2t

@@ -1,0 +1,236 @@
+// Mask preparation, embedding gathers, rotary tables and the QKV post-pass (head split, query
+// scale, rotary, V transpose).  All HBM-bound.
+//   ESM embeddings: HF EsmEmbeddings.forward, transformers/models/esm/modeling_esm.py:224-271
+//   Llama embed:    HF LlamaModel.forward, transformers/models/llama/modeling_llama.py:381
+//   rotary:         modeling_esm.py:48-79,141-160 / modeling_llama.py:108-160 (rotate-half layout)
+#include "common.h"
+#include "kernels.h"
+
+namespace p2t {
+
+// One block per batch row: key_mask u8, kv_info[b] = 1 + last valid key, kv_info[B+b] = prefix flag,
+// ESM token-dropout scale.
+__global__ void __launch_bounds__(256) mask_prepare_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+                                                           int T, int mask_id, int token_dropout,
+                                                           uint8_t* __restrict__ key_mask, int32_t* __restrict__ kv_info,
+                                                           float* __restrict__ emb_scale) {
+    __shared__ int s_end[4], s_cnt[4], s_nmask[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int end = 0, cnt = 0, nm = 0;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const int v = mask[(int64_t)b * T + t] != 0;
+        key_mask[(int64_t)b * T + t] = (uint8_t)v;
+        if (v) end = t + 1;
+        cnt += (int)mask[(int64_t)b * T + t];
+        if (ids) nm += (ids[(int64_t)b * T + t] == mask_id);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        end = max(end, __shfl_xor(end, o, 64));
+        cnt += __shfl_xor(cnt, o, 64);
+        nm += __shfl_xor(nm, o, 64);
+    }
+    if (lane == 0) { s_end[w] = end; s_cnt[w] = cnt; s_nmask[w] = nm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        end = max(max(s_end[0], s_end[1]), max(s_end[2], s_end[3]));
+        cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        nm = s_nmask[0] + s_nmask[1] + s_nmask[2] + s_nmask[3];
+        kv_info[b] = end;                                   // 1 + last valid key
+        kv_info[gridDim.x + b] = (cnt == end);              // mask is a plain prefix (right-padded contract)
+        if (emb_scale) {
+            // (1 - 0.15*0.8) / (1 - observed mask ratio), modeling_esm.py:256-262
+            const float ratio = (float)nm / (float)cnt;
+            emb_scale[b * 2 + 0] = token_dropout ? 0.88f : 1.0f;
+            emb_scale[b * 2 + 1] = token_dropout ? (1.0f - ratio) : 1.0f;
+        }
+    }
+}
+
+// x[m, :] = mask[m] * ((id == <mask> ? 0 : table[id]) * 0.88 / (1 - ratio_b)); one wave per token.
+template <typename T>
+__global__ void __launch_bounds__(256) esm_embed_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+                                                        const T* __restrict__ table, const float* __restrict__ emb_scale,
+                                                        int seq, int H, int vocab, int mask_id, int token_dropout,
+                                                        float* __restrict__ x, int64_t M) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = (int)(m / seq);
+    int64_t id = ids[m];
+    const float mk = (float)mask[m];
+    const bool zero = (token_dropout && id == mask_id) || id < 0 || id >= vocab;
+    if (zero) id = 0;
+    const float mul = emb_scale[b * 2 + 0], den = emb_scale[b * 2 + 1];
+    const T* row = table + id * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4];
+        load4(row + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float e = zero ? 0.f : v[j];
+            if (token_dropout) e = __fdiv_rn(__fmul_rn(e, mul), den);
+            v[j] = e * mk;
+        }
+        store4(x + m * H + c, v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) llama_embed_kernel(const int64_t* __restrict__ ids, const T* __restrict__ table,
+                                                          int H, int vocab, float* __restrict__ x, int64_t M) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    int64_t id = ids[m];
+    if (id < 0 || id >= vocab) id = 0;
+    const T* row = table + id * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4];
+        load4(row + c, v);
+        store4(x + m * H + c, v);
+    }
+}
+
+// inv_freq[j] = 1 / theta^(2j/d), optionally with the llama3 wavelength-dependent scaling
+// (transformers/modeling_rope_utils.py:580-662), evaluated in fp32 like the reference does.
+__global__ void inv_freq_kernel(float* __restrict__ inv_freq, int half, float theta, int llama3, float factor,
+                                float low_ff, float high_ff, float orig_max_pos) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    float inv = 1.0f / powf(theta, (float)(2 * j) / (float)(2 * half));
+    if (llama3) {
+        const float low_wl = orig_max_pos / low_ff, high_wl = orig_max_pos / high_ff;
+        const float wavelen = 6.283185307179586f / inv;
+        float inv_l = wavelen > low_wl ? inv / factor : inv;
+        const float smooth = (orig_max_pos / wavelen - low_ff) / (high_ff - low_ff);
+        const float smoothed = (1.0f - smooth) * inv_l / factor + smooth * inv_l;
+        const bool medium = !(wavelen < high_wl) && !(wavelen > low_wl);
+        inv = medium ? smoothed : inv_l;
+    }
+    inv_freq[j] = inv;
+}
+
+// cs[t, 0:half] = cos(t * inv_freq), cs[t, half:2*half] = sin(...)
+__global__ void __launch_bounds__(256) rope_table_kernel(const float* __restrict__ inv_freq, int T, int half,
+                                                         float* __restrict__ cs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * half) return;
+    const int t = i / half, j = i % half;
+    const float a = __fmul_rn((float)t, inv_freq[j]);
+    cs[(int64_t)t * 2 * half + j] = cosf(a);
+    cs[(int64_t)t * 2 * half + half + j] = sinf(a);
+}
+
+// grid (ceil(T/64), nh + 2*nkv, B).  qkv row m: [q heads | k heads | v heads], row stride ldq.
+// q: [B, nh, T, dp]  k: [B, nkv, T, dp] (scaled / rotated, zero padded to dp)
+// vt: [B, nkv, dp, tp] (transposed through LDS so both the read and the write are coalesced)
+template <typename T>
+__global__ void __launch_bounds__(256) qkv_post_kernel(const T* __restrict__ qkv, int64_t ldq, const float* __restrict__ cs,
+                                                       T* __restrict__ q, T* __restrict__ k, T* __restrict__ vt, int seq,
+                                                       int nh, int nkv, int d, int dp, int tp, float q_scale) {
+    __shared__ float tile[64][129];
+    const int b = blockIdx.z, hh = blockIdx.y, t0 = blockIdx.x * 64;
+    const int half = d / 2;
+    if (hh < nh + nkv) {
+        const bool is_q = hh < nh;
+        const int head = is_q ? hh : hh - nh;
+        const int col0 = is_q ? head * d : nh * d + head * d;
+        T* dst = is_q ? q + ((int64_t)(b * nh + head) * seq) * dp : k + ((int64_t)(b * nkv + head) * seq) * dp;
+        const float sc = is_q ? q_scale : 1.0f;
+        const int hp = dp / 2;                       // loop over (token, j in [0, dp/2))
+        for (int i = threadIdx.x; i < 64 * hp; i += 256) {
+            const int tl = i / hp, j = i % hp, t = t0 + tl;
+            if (t >= seq) continue;
+            float o1 = 0.f, o2 = 0.f;
+            const T* src = qkv + ((int64_t)b * seq + t) * ldq + col0;
+            if (j < half) {
+                const float x1 = to_f32(src[j]) * sc, x2 = to_f32(src[j + half]) * sc;
+                const float c = cs[(int64_t)t * d + j], s = cs[(int64_t)t * d + half + j];
+                o1 = x1 * c - x2 * s;
+                o2 = x2 * c + x1 * s;
+            }
+            // element j -> column j, element j+half -> column j+half; columns >= d are zero
+            T* row = dst + (int64_t)t * dp;
+            if (j < half) {
+                row[j] = from_f32<T>(o1);
+                row[j + half] = from_f32<T>(o2);
+            }
+            // zero pad: columns d .. dp-1 (covered by j in [half, hp) mapped to d + 2*(j-half) + {0,1})
+            if (j >= half) {
+                const int c0 = d + 2 * (j - half);
+                if (c0 < dp) row[c0] = from_f32<T>(0.f);
+                if (c0 + 1 < dp) row[c0 + 1] = from_f32<T>(0.f);
+            }
+        }
+    } else {
+        const int head = hh - nh - nkv;
+        const int col0 = (nh + nkv) * d + head * d;
+        for (int i = threadIdx.x; i < 64 * d; i += 256) {
+            const int tl = i / d, c = i % d, t = t0 + tl;
+            tile[tl][c] = t < seq ? to_f32(qkv[((int64_t)b * seq + t) * ldq + col0 + c]) : 0.f;
+        }
+        __syncthreads();
+        T* dst = vt + ((int64_t)(b * nkv + head) * dp) * tp;
+        for (int i = threadIdx.x; i < 64 * dp; i += 256) {
+            const int c = i / 64, tl = i % 64, t = t0 + tl;
+            if (t < tp) dst[(int64_t)c * tp + t] = from_f32<T>(c < d ? tile[tl][c] : 0.f);
+        }
+    }
+}
+
+int launch_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
+                        uint8_t* key_mask, int32_t* kv_info, float* emb_scale, hipStream_t s) {
+    mask_prepare_kernel<<<B, 256, 0, s>>>(ids, mask, T, mask_id, token_dropout, key_mask, kv_info, emb_scale);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+int launch_esm_embed(const int64_t* ids, const int64_t* mask, const void* table, int dtype, const float* emb_scale, int T,
+                     int H, int vocab, int mask_id, int token_dropout, float* x, int64_t M, hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(M, 4));
+    if (dtype == P2T_BF16)
+        esm_embed_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, mask, (const bf16_t*)table, emb_scale, T, H, vocab, mask_id, token_dropout, x, M);
+    else
+        esm_embed_kernel<float><<<grid, 256, 0, s>>>(ids, mask, (const float*)table, emb_scale, T, H, vocab, mask_id, token_dropout, x, M);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+int launch_llama_embed(const int64_t* ids, const void* table, int dtype, int H, int vocab, float* x, int64_t M,
+                       hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(M, 4));
+    if (dtype == P2T_BF16)
+        llama_embed_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, (const bf16_t*)table, H, vocab, x, M);
+    else
+        llama_embed_kernel<float><<<grid, 256, 0, s>>>(ids, (const float*)table, H, vocab, x, M);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+int launch_inv_freq(float* inv_freq, int half, float theta, int llama3, float factor, float low_ff, float high_ff,
+                    float orig_max_pos, hipStream_t s) {
+    inv_freq_kernel<<<ceil_div(half, 64), 64, 0, s>>>(inv_freq, half, theta, llama3, factor, low_ff, high_ff, orig_max_pos);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+int launch_rope_table(const float* inv_freq, int T, int half, float* cs, hipStream_t s) {
+    rope_table_kernel<<<ceil_div((int64_t)T * half, 256), 256, 0, s>>>(inv_freq, T, half, cs);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* vt, int B, int T, int nh,
+                    int nkv, int d, int dp, int tp, float q_scale, int dtype, hipStream_t s) {
+    P2T_REQUIRE(d % 2 == 0 && d <= 128 && dp >= d && dp <= 128 && dp % 2 == 0, "qkv_post: head_dim %d (padded %d) unsupported", d, dp);
+    const dim3 grid((unsigned)ceil_div(tp, 64), (unsigned)(nh + 2 * nkv), (unsigned)B);
+    if (dtype == P2T_BF16)
+        qkv_post_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)qkv, ldq, cs, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, T, nh, nkv, d, dp, tp, q_scale);
+    else
+        qkv_post_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, ldq, cs, (float*)q, (float*)k, (float*)vt, T, nh, nkv, d, dp, tp, q_scale);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+}  // namespace p2t

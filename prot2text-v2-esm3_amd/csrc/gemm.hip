@@ -1,0 +1,90 @@
+// GEMM and attention dispatch: argument checks, kernel choice (MFMA vs fp32-FMA), C entry points.
+#include "common.h"
+#include "epilogue.h"
+#include "kernels.h"
+
+namespace p2t {
+
+int gemm_nt(const GemmArgs& a, hipStream_t s) {
+    P2T_REQUIRE(a.A && a.W && a.out, "gemm_nt: null operand");
+    P2T_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0 && a.N < (1 << 30) && a.K < (1 << 30), "gemm_nt: bad sizes M=%lld N=%lld K=%lld",
+                (long long)a.M, (long long)a.N, (long long)a.K);
+    if (a.M == 0) return P2T_OK;
+    const bool swiglu = a.epilogue == P2T_EPI_SWIGLU;
+    P2T_REQUIRE(a.N % (swiglu ? 32 : 16) == 0, "gemm_nt: N=%lld must be a multiple of %d", (long long)a.N, swiglu ? 32 : 16);
+    P2T_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0 && a.lda >= a.K && a.ldw >= a.K,
+                "gemm_nt: K and the row strides must be multiples of 4 (K=%lld lda=%lld ldw=%lld ldc=%lld)", (long long)a.K,
+                (long long)a.lda, (long long)a.ldw, (long long)a.ldc);
+    const int n_out = swiglu ? (int)a.N / 2 : (int)a.N;
+    P2T_REQUIRE(a.ldc >= n_out, "gemm_nt: ldc=%lld < %d output columns", (long long)a.ldc, n_out);
+    int out_dtype = a.out_dtype;
+    if (a.epilogue == P2T_EPI_RESID || a.epilogue == P2T_EPI_STORE_F32) out_dtype = P2T_F32;
+    P2T_REQUIRE(a.epilogue != P2T_EPI_GELU_BWD || a.z, "gemm_nt: EPI_GELU_BWD needs z");
+
+    int n_zero = n_out;
+    if (a.epilogue == P2T_EPI_STORE || a.epilogue == P2T_EPI_GELU || swiglu || a.epilogue == P2T_EPI_GELU_BWD) {
+        n_zero = a.n_zero >= 0 ? a.n_zero : (int)(round_up(n_out, 64) < a.ldc ? round_up(n_out, 64) : a.ldc);
+        if (n_zero < n_out) n_zero = n_out;
+    }
+    const int n_cover = swiglu ? (int)(a.N > 2 * n_zero ? a.N : 2 * n_zero) : (int)(a.N > n_zero ? a.N : n_zero);
+
+    EpiParams ep;
+    ep.bias = a.bias; ep.out = a.out; ep.z = a.z; ep.ldc = a.ldc; ep.M = a.M; ep.N = (int)a.N; ep.n_zero = n_zero;
+    ep.accumulate = a.accumulate; ep.drop_p = a.drop_p; ep.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    ep.drop_seed = a.drop_seed;
+
+    const bool aligned = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0);
+    const bool can_mfma = a.dtype == P2T_BF16 && a.K % 64 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && aligned;
+    if (a.use_mfma == 1 && !can_mfma) {
+        set_error("gemm_nt: MFMA kernel required but shape/dtype not eligible (dtype=%d K=%lld lda=%lld ldw=%lld)", a.dtype,
+                  (long long)a.K, (long long)a.lda, (long long)a.ldw);
+        return P2T_ERR_UNSUPPORTED;
+    }
+    if (can_mfma && a.use_mfma != 0)
+        return launch_gemm_mfma(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, out_dtype, a.epilogue, ep, a.tile, s);
+    return launch_gemm_simple(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, a.dtype, out_dtype, a.epilogue, ep, s);
+}
+
+int attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+              int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal, int dtype,
+              int use_mfma, hipStream_t s) {
+    P2T_REQUIRE(q && k && vt && key_mask && kv_info && out && B > 0 && T > 0 && nh > 0 && nkv > 0, "attention: bad arguments");
+    P2T_REQUIRE(ld_out >= (int64_t)nh * d, "attention: ld_out too small");
+    if (dtype == P2T_BF16 && use_mfma != 0)
+        return launch_attn_mfma(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, s);
+    P2T_REQUIRE(use_mfma != 1, "attention: MFMA kernel needs bf16");
+    return launch_attn_simple(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, dtype, s);
+}
+
+}  // namespace p2t
+
+using namespace p2t;
+
+extern "C" int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
+                           void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
+                           int use_mfma, p2t_stream stream) {
+    GemmArgs a{A, lda, W, ldw, bias, out, ldc, z, M, N, K, dtype, out_dtype, epilogue, accumulate, use_mfma, -1, 0.f, 0, 0};
+    return gemm_nt(a, (hipStream_t)stream);
+}
+
+extern "C" int p2t_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
+                                uint8_t* key_mask, int32_t* kv_info, float* emb_scale, p2t_stream stream) {
+    P2T_REQUIRE(mask && key_mask && kv_info && B > 0 && T > 0, "p2t_mask_prepare: bad arguments");
+    return launch_mask_prepare(ids, mask, B, T, mask_id, token_dropout, key_mask, kv_info, emb_scale, (hipStream_t)stream);
+}
+
+extern "C" int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos_sin_scratch, void* q, void* k,
+                            void* vt, int B, int T, int nh, int nkv, int d, int dp, int tp, float q_scale, int dtype,
+                            p2t_stream stream) {
+    P2T_REQUIRE(qkv && inv_freq && cos_sin_scratch && q && k && vt, "p2t_qkv_post: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    P2T_TRY(launch_rope_table(inv_freq, T, d / 2, cos_sin_scratch, s));
+    return launch_qkv_post(qkv, ldq, cos_sin_scratch, q, k, vt, B, T, nh, nkv, d, dp, tp, q_scale, dtype, s);
+}
+
+extern "C" int p2t_attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info,
+                             void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale,
+                             int causal, int dtype, int use_mfma, p2t_stream stream) {
+    return attention(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, dtype, use_mfma,
+                     (hipStream_t)stream);
+}

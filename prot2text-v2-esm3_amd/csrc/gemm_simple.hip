@@ -1,0 +1,106 @@
+// fp32-FMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  with the shared epilogues.  This is the exact-fp32
+// path (dtype F32: parity mode, 1e-5 against the fp32 oracle) and the fallback for shapes the MFMA
+// kernel does not take; inputs of either dtype are widened to fp32 and accumulated with fmaf.
+// 64x128 block tile, 16-deep K slices staged through LDS, 4x8 outputs per thread.
+#include "common.h"
+#include "epilogue.h"
+#include "kernels.h"
+
+namespace p2t {
+
+template <typename T, typename Epi>
+__global__ void __launch_bounds__(256) gemm_nt_simple_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
+                                                             int64_t ldw, int64_t M, int N, int K, int n_cover,
+                                                             EpiParams ep) {
+    constexpr int BM = 64, BN = 128, BK = 16;
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Ws[BK][BN + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int nl = (tx >> 2) * 32 + (tx & 3) * 4;          // first column group; partner at nl + 16
+    float acc0[4][4], acc1[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = 0.f;
+
+    const int lr = tid >> 2, lk = (tid & 3) * 4;           // staging: row lr (+64), k offset lk
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool kin = k0 + lk < K;
+        if (kin && m0 + lr < M) load4(A + (m0 + lr) * lda + k0 + lk, a);
+        if (kin && n0 + lr < N) load4(W + (int64_t)(n0 + lr) * ldw + k0 + lk, w0);
+        if (kin && n0 + lr + 64 < N) load4(W + (int64_t)(n0 + lr + 64) * ldw + k0 + lk, w1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[lk + j][lr] = a[j];
+            Ws[lk + j][lr] = w0[j];
+            Ws[lk + j][lr + 64] = w1[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            float av[4], b0[4], b1[4];
+            load4(&As[kk][ty * 4], av);
+            load4(&Ws[kk][nl], b0);
+            load4(&Ws[kk][nl + 16], b1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0[i][j] = fmaf(av[i], b0[j], acc0[i][j]);
+                    acc1[i][j] = fmaf(av[i], b1[j], acc1[i][j]);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + ty * 4 + i;
+        if (m < M && n0 + nl < n_cover) Epi::apply2(ep, m, n0 + nl, acc0[i], acc1[i]);
+    }
+}
+
+template <typename T, typename Epi>
+static int launch_simple_t(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
+                           const EpiParams& ep, hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(n_cover, 128), (unsigned)ceil_div(M, 64));
+    gemm_nt_simple_kernel<T, Epi><<<grid, 256, 0, s>>>((const T*)A, lda, (const T*)W, ldw, M, N, K, n_cover, ep);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+template <typename T>
+static int dispatch_epi(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
+                        int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s) {
+    const bool ob = out_dtype == P2T_BF16;
+    switch (epilogue) {
+        case P2T_EPI_STORE:
+            return ob ? launch_simple_t<T, EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
+                      : launch_simple_t<T, EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_GELU:
+            return ob ? launch_simple_t<T, EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
+                      : launch_simple_t<T, EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_RESID:
+            return launch_simple_t<T, EpiResid>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_SWIGLU:
+            return ob ? launch_simple_t<T, EpiSwiglu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
+                      : launch_simple_t<T, EpiSwiglu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_STORE_F32:
+            return launch_simple_t<T, EpiF32>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_GELU_BWD:
+            return ob ? launch_simple_t<T, EpiGeluBwd<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
+                      : launch_simple_t<T, EpiGeluBwd<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+    }
+    set_error("gemm: unknown epilogue %d", epilogue);
+    return P2T_ERR_ARG;
+}
+
+int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
+                       int dtype, int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s) {
+    if (dtype == P2T_BF16) return dispatch_epi<bf16_t>(A, lda, W, ldw, M, N, K, n_cover, out_dtype, epilogue, ep, s);
+    return dispatch_epi<float>(A, lda, W, ldw, M, N, K, n_cover, out_dtype, epilogue, ep, s);
+}
+
+}  // namespace p2t

@@ -1,0 +1,71 @@
+// Internal launchers shared between translation units (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+namespace p2t {
+
+struct EpiParams;
+
+int launch_colsum(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate, hipStream_t s);
+
+int launch_layernorm(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* y, int64_t ld_y,
+                     int64_t rows, int64_t cols, int out_dtype, hipStream_t s);
+int launch_rmsnorm(const float* x, int64_t ld_x, const float* w, float eps, void* y, int64_t ld_y, int64_t rows,
+                   int64_t cols, int out_dtype, hipStream_t s);
+int launch_l2norm(const void* x, int in_dtype, int64_t ld_x, void* y, int out_dtype, int64_t ld_y, float* inv_norm,
+                  int64_t rows, int64_t cols, float eps, hipStream_t s);
+
+int launch_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
+                        uint8_t* key_mask, int32_t* kv_info, float* emb_scale, hipStream_t s);
+int launch_esm_embed(const int64_t* ids, const int64_t* mask, const void* table, int dtype, const float* emb_scale, int T,
+                     int H, int vocab, int mask_id, int token_dropout, float* x, int64_t M, hipStream_t s);
+int launch_llama_embed(const int64_t* ids, const void* table, int dtype, int H, int vocab, float* x, int64_t M, hipStream_t s);
+int launch_inv_freq(float* inv_freq, int half, float theta, int llama3, float factor, float low_ff, float high_ff,
+                    float orig_max_pos, hipStream_t s);
+int launch_rope_table(const float* inv_freq, int T, int half, float* cs, hipStream_t s);
+int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* vt, int B, int T, int nh, int nkv,
+                    int d, int dp, int tp, float q_scale, int dtype, hipStream_t s);
+
+int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int dtype,
+                       int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s);
+int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
+                     int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s);
+// full dispatcher behind p2t_gemm_nt (gemm.hip)
+struct GemmArgs {
+    const void* A; int64_t lda; const void* W; int64_t ldw; const float* bias; void* out; int64_t ldc; void* z;
+    int64_t M; int64_t N; int64_t K; int dtype; int out_dtype; int epilogue; int accumulate; int use_mfma;
+    int n_zero;                 // -1: default (next multiple of 64, clipped to ldc)
+    float drop_p; uint64_t drop_seed;
+    int tile;                   // 0 auto, 128, 256
+};
+int gemm_nt(const GemmArgs& a, hipStream_t s);
+
+int launch_attn_simple(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+                       int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal, int dtype,
+                       hipStream_t s);
+int launch_attn_mfma(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal,
+                     hipStream_t s);
+int attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+              int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal, int dtype,
+              int use_mfma, hipStream_t s);
+
+// adapter tail helpers (adapter.hip)
+int launch_adapter_dz2(const void* g2, const void* z2, const float* inv_norm, const float* dy, void* dz2, int64_t ld, int64_t M,
+                       int D, int dtype, float drop_p, uint64_t drop_seed, hipStream_t s);
+
+// bump allocator over a caller-provided workspace
+struct Arena {
+    char* base; size_t size; size_t off = 0; bool overflow = false;
+    Arena(void* b, size_t n) : base((char*)b), size(n) {}
+    void* take(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        if (a + bytes > size) { overflow = true; off = a + bytes; return base; }
+        off = a + bytes;
+        return base + a;
+    }
+};
+
+static inline int head_dim_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
+
+}  // namespace p2t

@@ -1,0 +1,191 @@
+// Error string, synthetic fill, cast, transpose, column sums.  All HBM-bound streaming kernels:
+// 16 B per lane, grid-stride, <= 2048 blocks (cdna_hip_programming.md Guideline 11/13).
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace p2t {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) fill_hash_kernel(T* __restrict__ dst, int64_t n, uint64_t add, uint64_t xorv,
+                                                        float scale23, float offset) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t h = mix64(((uint64_t)(i + j) + add) ^ xorv);
+            const int u = (int)(h >> 40) - 8388608;
+            v[j] = __fadd_rn(__fmul_rn((float)u, scale23), offset);    // two roundings, never an FMA
+        }
+        if (i + 3 < n) {
+            store4(dst + i, v);
+        } else {
+            for (int j = 0; j < 4 && i + j < n; ++j) dst[i + j] = from_f32<T>(v[j]);
+        }
+    }
+}
+
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float v[4];
+            load4(src + i, v);
+            store4(dst + i, v);
+        } else {
+            for (int j = 0; j < 4 && i + j < n; ++j) dst[i + j] = from_f32<D>(to_f32(src[i + j]));
+        }
+    }
+}
+
+// 64x64 tile transpose through LDS (padded: conflict-free column reads).
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ src, int64_t rows, int64_t cols,
+                                                        int64_t ld_src, T* __restrict__ dst, int64_t ld_dst) {
+    __shared__ T tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[r * ld_src + c] : from_f32<T>(0.f);
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < cols && r < ld_dst) dst[c * ld_dst + r] = tile[tx][i];      // rows..ld_dst-1: zero K padding
+    }
+}
+
+// out[c] (+)= sum_r x[r, c]; one block per 64 columns, 4 waves stride the rows.
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                     float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    float acc = 0.f;
+    if (c < cols)
+        for (int64_t r = ty; r < rows; r += 4) acc += to_f32(x[r * ld + c]);
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        const float s = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
+// x[i] *= s[0]  (s lives on the device: chain-rule scaling without a host sync)
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ s) {
+    const float f = s[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= f;
+}
+
+static inline int stream_grid(int64_t n_items, int per_block) {
+    int64_t g = ceil_div(n_items, per_block);
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+int launch_colsum(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate,
+                  hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(cols, 64));
+    if (dtype == P2T_BF16)
+        colsum_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, rows, cols, ld, out, accumulate);
+    else
+        colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)x, rows, cols, ld, out, accumulate);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+}  // namespace p2t
+
+using namespace p2t;
+
+extern "C" int p2t_version(void) { return P2T_VERSION; }
+extern "C" const char* p2t_last_error(void) { return g_err; }
+extern "C" size_t p2t_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(p2t_esm2_config);
+        case 1: return sizeof(p2t_esm2_layer);
+        case 2: return sizeof(p2t_esm2_weights);
+        case 3: return sizeof(p2t_llama_config);
+        case 4: return sizeof(p2t_llama_layer);
+        case 5: return sizeof(p2t_llama_weights);
+        case 6: return sizeof(p2t_adapter_config);
+        case 7: return sizeof(p2t_adapter_weights);
+        case 8: return sizeof(p2t_adapter_saved);
+    }
+    return 0;
+}
+
+extern "C" int p2t_fill_hash(void* dst, int64_t n, uint64_t add, uint64_t xorv, float scale23, float offset, int dtype,
+                             p2t_stream stream) {
+    P2T_REQUIRE(dst && n >= 0, "p2t_fill_hash: bad arguments");
+    if (n == 0) return P2T_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = stream_grid(n, 1024);
+    if (dtype == P2T_BF16)
+        fill_hash_kernel<bf16_t><<<grid, 256, 0, s>>>((bf16_t*)dst, n, add, xorv, scale23, offset);
+    else if (dtype == P2T_F32)
+        fill_hash_kernel<float><<<grid, 256, 0, s>>>((float*)dst, n, add, xorv, scale23, offset);
+    else
+        P2T_REQUIRE(false, "p2t_fill_hash: dtype %d", dtype);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_scale_by_device_scalar(float* x, int64_t n, const float* scalar, p2t_stream stream) {
+    P2T_REQUIRE(x && scalar && n >= 0, "p2t_scale_by_device_scalar: bad arguments");
+    if (n == 0) return P2T_OK;
+    scale_kernel<<<stream_grid(n, 1024), 256, 0, (hipStream_t)stream>>>(x, n, scalar);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_cast(const void* src, int sd, void* dst, int dd, int64_t n, p2t_stream stream) {
+    P2T_REQUIRE(src && dst && n >= 0, "p2t_cast: bad arguments");
+    if (n == 0) return P2T_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = stream_grid(n, 1024);
+    if (sd == P2T_F32 && dd == P2T_BF16)
+        cast_kernel<float, bf16_t><<<grid, 256, 0, s>>>((const float*)src, (bf16_t*)dst, n);
+    else if (sd == P2T_BF16 && dd == P2T_F32)
+        cast_kernel<bf16_t, float><<<grid, 256, 0, s>>>((const bf16_t*)src, (float*)dst, n);
+    else if (sd == P2T_F32 && dd == P2T_F32)
+        cast_kernel<float, float><<<grid, 256, 0, s>>>((const float*)src, (float*)dst, n);
+    else if (sd == P2T_BF16 && dd == P2T_BF16)
+        cast_kernel<bf16_t, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, n);
+    else
+        P2T_REQUIRE(false, "p2t_cast: dtypes %d -> %d", sd, dd);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, void* dst, int64_t ld_dst,
+                             int dtype, p2t_stream stream) {
+    P2T_REQUIRE(src && dst && rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= rows, "p2t_transpose: bad arguments");
+    if (rows == 0 || cols == 0) return P2T_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64));
+    P2T_REQUIRE(grid.y <= 65535, "p2t_transpose: too many rows (%lld)", (long long)rows);
+    if (dtype == P2T_BF16)
+        transpose_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)src, rows, cols, ld_src, (bf16_t*)dst, ld_dst);
+    else
+        transpose_kernel<float><<<grid, 256, 0, s>>>((const float*)src, rows, cols, ld_src, (float*)dst, ld_dst);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}

@@ -1,0 +1,183 @@
+// Tower forwards: host-side launch sequences (no Python between kernels, no allocation, no sync;
+// capturable in a hipGraph).  Residual stream is fp32; GEMM operands are `dtype` (bf16 or fp32).
+//
+//   p2t_esm2_forward         HF EsmModel.forward (transformers/models/esm/modeling_esm.py:685-755)
+//                            as called by reference models/modeling_esm2llama_instruct.py:175-185
+//   p2t_llama_hidden_forward HF LlamaModel.forward (transformers/models/llama/modeling_llama.py:367-417)
+//                            as called by reference scripts/train_contrast.py:292-304
+#include "common.h"
+#include "kernels.h"
+
+using namespace p2t;
+
+namespace {
+
+struct EsmBuffers {
+    uint8_t* key_mask; int32_t* kv_info; float* emb_scale; float* inv_freq; float* cs;
+    float* x; void* h; void* qkv; void* q; void* k; void* vt; void* ao; void* ffn;
+};
+
+size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b) {
+    const size_t e = dtype_size(c->dtype);
+    const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
+    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads;
+    Arena local(nullptr, ~(size_t)0 >> 1);
+    Arena& a = ar ? *ar : local;
+    EsmBuffers t;
+    t.key_mask = (uint8_t*)a.take((size_t)M);
+    t.kv_info = (int32_t*)a.take(sizeof(int32_t) * 2 * B);
+    t.emb_scale = (float*)a.take(sizeof(float) * 2 * B);
+    t.inv_freq = (float*)a.take(sizeof(float) * (d / 2 + 1));
+    t.cs = (float*)a.take(sizeof(float) * (size_t)T * d);
+    t.x = (float*)a.take(sizeof(float) * (size_t)M * H);
+    t.h = a.take(e * (size_t)M * Hp);
+    t.qkv = a.take(e * (size_t)M * 3 * H);
+    t.q = a.take(e * (size_t)B * nh * T * dp);
+    t.k = a.take(e * (size_t)B * nh * T * dp);
+    t.vt = a.take(e * (size_t)B * nh * dp * tp);
+    t.ao = a.take(e * (size_t)M * Hp);
+    t.ffn = a.take(e * (size_t)M * Fp);
+    if (b) *b = t;
+    return a.off + 256;
+}
+
+struct LlamaBuffers {
+    uint8_t* key_mask; int32_t* kv_info; float* inv_freq; float* cs;
+    float* x; void* h; void* qkv; void* q; void* k; void* vt; void* ao; void* act;
+};
+
+size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffers* b) {
+    const size_t e = dtype_size(c->dtype);
+    const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
+    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads, nkv = c->kv_heads;
+    const int64_t QO = round_up((int64_t)nh * d, 64);
+    Arena local(nullptr, ~(size_t)0 >> 1);
+    Arena& a = ar ? *ar : local;
+    LlamaBuffers t;
+    t.key_mask = (uint8_t*)a.take((size_t)M);
+    t.kv_info = (int32_t*)a.take(sizeof(int32_t) * 2 * B);
+    t.inv_freq = (float*)a.take(sizeof(float) * (d / 2 + 1));
+    t.cs = (float*)a.take(sizeof(float) * (size_t)T * d);
+    t.x = (float*)a.take(sizeof(float) * (size_t)M * H);
+    t.h = a.take(e * (size_t)M * Hp);
+    t.qkv = a.take(e * (size_t)M * (nh + 2 * nkv) * d);
+    t.q = a.take(e * (size_t)B * nh * T * dp);
+    t.k = a.take(e * (size_t)B * nkv * T * dp);
+    t.vt = a.take(e * (size_t)B * nkv * dp * tp);
+    t.ao = a.take(e * (size_t)M * QO);
+    t.act = a.take(e * (size_t)M * Fp);
+    if (b) *b = t;
+    return a.off + 256;
+}
+
+}  // namespace
+
+extern "C" size_t p2t_esm2_workspace_bytes(const p2t_esm2_config* cfg, int B, int T) {
+    if (!cfg || B <= 0 || T <= 0) return 0;
+    return esm_plan(cfg, B, T, nullptr, nullptr);
+}
+
+extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights* w, const int64_t* ids, const int64_t* mask,
+                                int B, int T, void* out, int64_t ld_out, void* workspace, size_t workspace_bytes,
+                                p2t_stream stream) {
+    P2T_REQUIRE(c && w && ids && mask && out && workspace && B > 0 && T > 0, "p2t_esm2_forward: null/empty argument");
+    P2T_REQUIRE(c->hidden == c->heads * c->head_dim && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 16 == 0,
+                "p2t_esm2_forward: unsupported shape hidden=%d heads=%d head_dim=%d ffn=%d", c->hidden, c->heads, c->head_dim, c->ffn);
+    P2T_REQUIRE(ld_out >= c->hidden && ld_out % 4 == 0, "p2t_esm2_forward: ld_out");
+    P2T_REQUIRE(w->layers && w->word_emb && w->final_ln_w && w->final_ln_b, "p2t_esm2_forward: missing weights");
+    P2T_REQUIRE(workspace_bytes >= p2t_esm2_workspace_bytes(c, B, T), "p2t_esm2_forward: workspace too small (%zu < %zu)",
+                workspace_bytes, p2t_esm2_workspace_bytes(c, B, T));
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(workspace, workspace_bytes);
+    EsmBuffers b;
+    esm_plan(c, B, T, &ar, &b);
+    P2T_REQUIRE(!ar.overflow, "p2t_esm2_forward: workspace overflow");
+    const int dt = c->dtype;
+    const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
+    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads;
+
+    P2T_TRY(launch_mask_prepare(ids, mask, B, T, c->mask_id, c->token_dropout, b.key_mask, b.kv_info, b.emb_scale, s));
+    P2T_TRY(launch_esm_embed(ids, mask, w->word_emb, dt, b.emb_scale, T, (int)H, c->vocab, c->mask_id, c->token_dropout, b.x, M, s));
+    if (c->emb_layer_norm_before) {
+        // LayerNorm of the embeddings, then re-apply the attention mask (modeling_esm.py:264-268)
+        set_error("p2t_esm2_forward: emb_layer_norm_before=True is not an ESM2 configuration");
+        return P2T_ERR_UNSUPPORTED;
+    }
+    const float* inv_freq = w->inv_freq;
+    if (!inv_freq) {
+        P2T_TRY(launch_inv_freq(b.inv_freq, d / 2, c->rope_theta, 0, 1.f, 1.f, 1.f, 1.f, s));
+        inv_freq = b.inv_freq;
+    }
+    P2T_TRY(launch_rope_table(inv_freq, T, d / 2, b.cs, s));
+    const float q_scale = 1.0f / sqrtf((float)d);           // ESM scales q before rotary; SDPA scale is 1.0
+    for (int l = 0; l < c->n_layers; ++l) {
+        const p2t_esm2_layer& L = w->layers[l];
+        P2T_TRY(launch_layernorm(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
+        GemmArgs g1{b.h, Hp, L.qkv_w, Hp, L.qkv_b, b.qkv, 3 * H, nullptr, M, 3 * H, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)(3 * H), 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g1, s));
+        P2T_TRY(launch_qkv_post(b.qkv, 3 * H, b.cs, b.q, b.k, b.vt, B, T, nh, nh, d, dp, tp, q_scale, dt, s));
+        P2T_TRY(attention(b.q, b.k, b.vt, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, tp, 1.0f, 0, dt, -1, s));
+        GemmArgs g2{b.ao, Hp, L.o_w, Hp, L.o_b, b.x, H, nullptr, M, H, Hp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g2, s));
+        P2T_TRY(launch_layernorm(b.x, H, L.ln2_w, L.ln2_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
+        GemmArgs g3{b.h, Hp, L.fc1_w, Hp, L.fc1_b, b.ffn, Fp, nullptr, M, F, Hp, dt, dt, P2T_EPI_GELU, 0, -1, -1, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g3, s));
+        GemmArgs g4{b.ffn, Fp, L.fc2_w, Fp, L.fc2_b, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g4, s));
+    }
+    return launch_layernorm(b.x, H, w->final_ln_w, w->final_ln_b, c->layer_norm_eps, out, ld_out, M, H, dt, s);
+}
+
+extern "C" size_t p2t_llama_workspace_bytes(const p2t_llama_config* cfg, int B, int T) {
+    if (!cfg || B <= 0 || T <= 0) return 0;
+    return llama_plan(cfg, B, T, nullptr, nullptr);
+}
+
+extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids,
+                                        const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                                        size_t workspace_bytes, p2t_stream stream) {
+    P2T_REQUIRE(c && w && ids && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
+    P2T_REQUIRE(k >= 0 && k <= c->n_layers, "p2t_llama_hidden_forward: hidden_states[%d] out of range for %d layers", k, c->n_layers);
+    P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 16 == 0,
+                "p2t_llama_hidden_forward: unsupported shape");
+    P2T_REQUIRE(w->embed && (k == 0 || w->layers) && (k < c->n_layers || w->final_norm_w), "p2t_llama_hidden_forward: missing weights");
+    P2T_REQUIRE(workspace_bytes >= p2t_llama_workspace_bytes(c, B, T), "p2t_llama_hidden_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(workspace, workspace_bytes);
+    LlamaBuffers b;
+    llama_plan(c, B, T, &ar, &b);
+    P2T_REQUIRE(!ar.overflow, "p2t_llama_hidden_forward: workspace overflow");
+    const int dt = c->dtype;
+    const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
+    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads, nkv = c->kv_heads;
+    const int64_t NQKV = (int64_t)(nh + 2 * nkv) * d, QO = round_up((int64_t)nh * d, 64);
+
+    P2T_TRY(launch_mask_prepare(nullptr, mask, B, T, -1, 0, b.key_mask, b.kv_info, nullptr, s));
+    P2T_TRY(launch_llama_embed(ids, w->embed, dt, (int)H, c->vocab, b.x, M, s));
+    const float* inv_freq = w->inv_freq;
+    if (!inv_freq) {
+        P2T_TRY(launch_inv_freq(b.inv_freq, d / 2, c->rope_theta, c->rope_llama3, c->rope_factor, c->rope_low_freq_factor,
+                                c->rope_high_freq_factor, (float)c->rope_original_max_pos, s));
+        inv_freq = b.inv_freq;
+    }
+    P2T_TRY(launch_rope_table(inv_freq, T, d / 2, b.cs, s));
+    const float scale = 1.0f / sqrtf((float)d);
+    for (int l = 0; l < k; ++l) {
+        const p2t_llama_layer& L = w->layers[l];
+        P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
+        GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g1, s));
+        P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.vt, B, T, nh, nkv, d, dp, tp, 1.0f, dt, s));
+        P2T_TRY(attention(b.q, b.k, b.vt, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, tp, scale, 1, dt, -1, s));
+        GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g2, s));
+        P2T_TRY(launch_rmsnorm(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
+        GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, b.act, Fp, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_SWIGLU, 0, -1, -1, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g3, s));
+        GemmArgs g4{b.act, Fp, L.down_w, Fp, nullptr, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        P2T_TRY(gemm_nt(g4, s));
+    }
+    if (k == c->n_layers) return launch_rmsnorm(b.x, H, w->final_norm_w, c->rms_norm_eps, out, H, M, H, P2T_F32, s);
+    P2T_CHECK_HIP(hipMemcpyAsync(out, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
+    return P2T_OK;
+}

@@ -1,0 +1,364 @@
+"""The contrastive-alignment step: host-side mirror of the reference's scripts/train_contrast.py.
+
+Same public names and argument meaning as the reference functions they replace:
+
+    BatchInfoNCELoss / SegmentedBatchInfoNCELoss     scripts/train_contrast.py:72-114
+    readout_embeddings                               :198-248
+    get_sequence_embeddings                          :251-281  (ESM2 variant: ids + mask)
+    get_description_embeddings                       :284-310
+    teacher_forcing_forward_pass                     :313-379
+
+plus `ContrastiveTrainer`, the fused step the benchmark times: text tower (16 layers) -> ESM2 ->
+adapter -> readout -> normalise -> InfoNCE -> adapter backward -> clip + AdamW, enqueued without a
+host sync, with the batch sharded over ranks (each rank encodes its slice, text embeddings are
+all-gathered over RCCL so every rank scores its rows against the GLOBAL batch).
+
+All arithmetic runs in libp2t_hip.so; autograd.Functions below only wire the hand-written
+backward kernels into torch's graph so `loss.backward()` works in an existing training loop.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Any, Dict, Literal, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import _lib, ops
+from ._lib import call
+from .ops import ptr, round_up, stream
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd wiring
+# ---------------------------------------------------------------------------------------------
+class _ReadoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, mask, mode):
+        out = ops.readout(emb, mask, mode)
+        if mode in ("std", "mix"):
+            pooled = out if mode == "mix" else ops.readout(emb, mask, "mix")
+        else:
+            pooled = None
+        ctx.mode, ctx.mask = mode, mask
+        ctx.save_for_backward(emb, pooled) if pooled is not None else ctx.save_for_backward(emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        saved = ctx.saved_tensors
+        emb, pooled = saved[0], (saved[1] if len(saved) > 1 else None)
+        d_emb = ops.readout_backward(emb, ctx.mask, ctx.mode, pooled, d_out.float())
+        return (d_emb if emb.dtype == torch.float32 else ops.cast(d_emb, emb.dtype)), None, None
+
+
+class _NormalizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.l2norm_rows(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.l2norm_rows_backward(x, dy)
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, batch, labels, temperature):
+        loss, logits = ops.infonce_forward(seg, batch, labels, temperature)
+        ctx.save_for_backward(batch, labels, logits)
+        ctx.temperature = temperature
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        batch, labels, logits = ctx.saved_tensors
+        d = ops.infonce_backward(batch, labels, logits, ctx.temperature, 1.0)
+        call("p2t_scale_by_device_scalar", ptr(d), d.numel(), ptr(g.float().reshape(1).contiguous()), stream())
+        return d, None, None, None
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """torch.nn.functional.normalize(x, p=2, dim=-1) for [rows, cols] embeddings (train_contrast.py:354,365)."""
+    if x.dim() != 2:
+        raise ValueError("l2_normalize expects pooled [batch, dim] embeddings")
+    x = x.float().contiguous()
+    return _NormalizeFn.apply(x) if x.requires_grad and torch.is_grad_enabled() else ops.l2norm_rows(x)
+
+
+def readout_embeddings(embeddings: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                       readout_fn: Literal["last", "mean", "std", "mix"]) -> torch.Tensor:
+    """Readout over the sequence axis given the attention mask -> f32 (bsz, hidden) or (bsz, 2*hidden).
+    "last" assumes right padding, "std" is the population std with no eps (reference :207-248)."""
+    if readout_fn not in ("last", "mean", "std", "mix"):
+        raise ValueError(f"readout_fn must be one of 'last', 'mean', 'std', 'mix', got {readout_fn!r}")
+    if embeddings.dim() != 3:
+        raise ValueError("embeddings must be (bsz, seq_len, hidden_dim)")
+    emb = embeddings
+    if emb.stride(2) != 1 or emb.stride(0) != emb.shape[1] * emb.stride(1):
+        emb = emb.contiguous()
+    if emb.requires_grad and torch.is_grad_enabled():
+        return _ReadoutFn.apply(emb, attention_mask, readout_fn)
+    return ops.readout(emb, attention_mask, readout_fn)
+
+
+class SegmentedBatchInfoNCELoss(nn.Module):
+    """Row-wise InfoNCE of a segment against the whole batch (reference :94-114):
+    logits = seg @ batch.T / temperature; loss = -mean_i log softmax(logits_i)[labels_i]."""
+
+    def __init__(self, temperature: float = 0.05):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, segment_output1: torch.Tensor, batch_output2: torch.Tensor, labels: torch.Tensor):
+        if segment_output1.dim() != 2 or batch_output2.dim() != 2 or segment_output1.shape[1] != batch_output2.shape[1]:
+            raise ValueError("expected segment_output1 (segment_size, dim) and batch_output2 (bsz, dim)")
+        if labels.numel() != segment_output1.shape[0]:
+            raise ValueError("labels must hold one target index per segment row")
+        if batch_output2.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("gradients flow to the first argument only (the text side is frozen on this path)")
+        seg = segment_output1.float().contiguous()
+        bat = batch_output2.detach().float().contiguous()
+        return _InfoNCEFn.apply(seg, bat, labels, float(self.temperature))
+
+
+class BatchInfoNCELoss(nn.Module):
+    """In-batch InfoNCE, positives on the diagonal (reference :72-91)."""
+
+    def __init__(self, temperature: float = 0.05):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, batch_output1: torch.Tensor, batch_output2: torch.Tensor):
+        if batch_output1.shape != batch_output2.shape:
+            raise ValueError("BatchInfoNCELoss expects two (bsz, dim) tensors of the same shape")
+        labels = torch.arange(batch_output1.shape[0], device=batch_output1.device)
+        return SegmentedBatchInfoNCELoss(self.temperature)(batch_output1, batch_output2, labels)
+
+
+# ---------------------------------------------------------------------------------------------
+# embedding getters + the step, as the reference spells them
+# ---------------------------------------------------------------------------------------------
+def get_sequence_embeddings(model, protein_input_ids: torch.Tensor, protein_attention_mask: torch.Tensor,
+                            readout_fn: str = "mix", ones_mask: bool = False) -> torch.Tensor:
+    """Pooled adapter outputs for contrastive learning (reference :251-281).  `ones_mask=True` reproduces
+    the fork's all-ones readout mask (:269-275); the default pools valid tokens only."""
+    adapter_output, _ = model(protein_input_ids=protein_input_ids, protein_attention_mask=protein_attention_mask,
+                              return_adapter_outputs=True)
+    mask = None if ones_mask else protein_attention_mask
+    return readout_embeddings(adapter_output, mask, readout_fn)
+
+
+def get_description_embeddings(model, description_input_ids: torch.Tensor, description_attention_mask: torch.Tensor,
+                               output_llm_layer: int = 16, readout_fn: str = "mix") -> torch.Tensor:
+    """hidden_states[output_llm_layer] of the frozen text tower, pooled (reference :284-310)."""
+    decoder = getattr(model, "llama_decoder", None) or model.llm_decoder
+    with torch.no_grad():
+        outputs = decoder.model(input_ids=description_input_ids, attention_mask=description_attention_mask,
+                                use_cache=False, output_attentions=False, output_hidden_states=True, return_dict=True)
+        hidden_states = outputs.hidden_states[output_llm_layer]
+    return readout_embeddings(hidden_states, description_attention_mask, readout_fn)
+
+
+def _gather_text(t_local: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:
+    """All-gather the (no-grad) normalised text embeddings: returns ([world*B_loc, D], this rank's row offset)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t_local, 0
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out = torch.empty((world * t_local.shape[0], t_local.shape[1]), dtype=t_local.dtype, device=t_local.device)
+    dist.all_gather_into_tensor(out, t_local.contiguous(), group=group)
+    return out, rank * t_local.shape[0]
+
+
+def teacher_forcing_forward_pass(rank, model, data_batch: Dict[str, Any], contrastive_num_segments: int, *,
+                                 output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
+                                 global_negatives: bool = False, temperature: float = 0.05) -> torch.Tensor:
+    """One forward of the contrastive step (reference :313-379); the returned loss carries the autograd
+    graph through the adapter.  `global_negatives=True` scores against the all-gathered global batch
+    (the reference uses per-rank negatives; with world size 1 the two coincide)."""
+    base = model.module if hasattr(model, "module") else model
+    dev = next(base.adapter.parameters()).device
+    pid = data_batch["protein_input_ids"].to(dev)
+    pmask = data_batch["protein_attention_mask"].to(dev)
+    tid = data_batch["description_input_ids"].to(dev)
+    tmask = data_batch["description_attention_mask"].to(dev)
+    batch_size = pid.shape[0]
+    segment_size = batch_size // contrastive_num_segments
+    if segment_size * contrastive_num_segments != batch_size:
+        print("WARNING: Given batch size is not divisible by the number of segments for contrastive learning.")
+    with torch.no_grad():
+        description_output = l2_normalize(get_description_embeddings(base, tid, tmask, output_llm_layer, readout_fn))
+    offset = 0
+    if global_negatives:
+        description_output, offset = _gather_text(description_output)
+    loss_fn = SegmentedBatchInfoNCELoss(temperature)
+    acc_loss = torch.zeros([], device=dev)
+    for s in range(contrastive_num_segments):
+        sl = slice(s * segment_size, (s + 1) * segment_size)
+        seg = l2_normalize(get_sequence_embeddings(base, pid[sl], pmask[sl], readout_fn, ones_mask))
+        labels = torch.arange(sl.start, sl.stop, device=dev) + offset
+        acc_loss = acc_loss + loss_fn(segment_output1=seg, batch_output2=description_output, labels=labels)
+    return acc_loss / contrastive_num_segments
+
+
+# ---------------------------------------------------------------------------------------------
+# fused training step
+# ---------------------------------------------------------------------------------------------
+class ContrastiveTrainer:
+    """The timed step: forward + adapter backward + clip + AdamW in one enqueue sequence.
+
+    Adapter parameters are kept as fp32 masters (with fp32 Adam moments) in ONE flat buffer -- so
+    the multi-GPU gradient exchange is a single RCCL all-reduce per optimizer step -- plus GEMM-layout
+    copies in the tower dtype that the AdamW kernel refreshes.  `sync_to_module()` writes the masters
+    back into `model.adapter` (checkpoint keys fc1/fc2.weight/bias as upstream).
+    Hyper-parameters default to the reference's: AdamW(lr=2e-4, eps=1e-6, betas=(0.9, 0.999)), weight decay
+    0.01 (torch default), no clipping, dropout from the adapter config (train mode).
+    """
+
+    def __init__(self, model, *, lr=2e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=None,
+                 num_segments: int = 1, output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
+                 temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None):
+        self.model = model
+        self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                       max_norm=math.inf if max_norm is None else max_norm)
+        self.num_segments, self.layer, self.readout_fn = num_segments, output_llm_layer, readout_fn
+        self.ones_mask, self.temperature, self.train_mode = ones_mask, temperature, train_mode
+        self.global_negatives, self.group = global_negatives, process_group
+        self.step_count = 0
+        ad = model.adapter
+        c = ad.config
+        self.c = c
+        dev = ad.fc1.weight.device
+        self.dev = dev
+        self.tdt = model.esm_encoder.dtype
+        shapes = [(c.intermediate_dim, c.input_dim), (c.intermediate_dim,), (c.output_dim, c.intermediate_dim), (c.output_dim,)]
+        sizes = [math.prod(s) for s in shapes]
+        tot = sum(sizes)
+        self.flat_p = torch.empty((tot,), dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros((tot,), dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros((tot,), dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros((tot,), dtype=torch.float32, device=dev)
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        view = lambda flat: [flat[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(4)]
+        self.p, self.g, self.m, self.v = view(self.flat_p), view(self.flat_g), view(self.flat_m), view(self.flat_v)
+        with torch.no_grad():
+            for dst, src in zip(self.p, (ad.fc1.weight, ad.fc1.bias, ad.fc2.weight, ad.fc2.bias)):
+                dst.copy_(src.detach().float())
+        K1, ld1 = round_up(c.input_dim, 64), round_up(c.intermediate_dim, 64)
+        self.w1 = torch.zeros((c.intermediate_dim, K1), dtype=self.tdt, device=dev)
+        self.w2 = torch.zeros((c.output_dim, ld1), dtype=self.tdt, device=dev)
+        self.w1[:, : c.input_dim].copy_(self.p[0])
+        self.w2[:, : c.intermediate_dim].copy_(self.p[2])
+        self.scratch = torch.empty((256 * 4,), dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self._buf = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _buffers(self, Bs: int, T: int):
+        key = (Bs, T)
+        b = self._buf.get(key)
+        if b is None:
+            c, dev, dt = self.c, self.dev, self.tdt
+            M = Bs * T
+            ld1, ld2 = round_up(c.intermediate_dim, 64), round_up(c.output_dim, 64)
+            e = lambda *s, d=dt: torch.empty(s, dtype=d, device=dev)
+            b = dict(z1=e(M, ld1), h1=e(M, ld1), z2=e(M, ld2), g2=e(M, ld2), y=e(M, ld2),
+                     inv=e(M, d=torch.float32), dY=e(M, c.output_dim, d=torch.float32))
+            cfg = _lib.AdapterConfigC(input_dim=c.input_dim, intermediate_dim=c.intermediate_dim, output_dim=c.output_dim,
+                                      dropout_p=0.0, dropout_seed=0, dtype=ops.dt_of(dt))
+            nbytes = call("p2t_adapter_backward_workspace_bytes", C.byref(cfg), M)
+            b["ws"] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            b["saved"] = _lib.AdapterSavedC(z1=b["z1"].data_ptr(), h1=b["h1"].data_ptr(), z2=b["z2"].data_ptr(),
+                                            g2=b["g2"].data_ptr(), inv_norm=b["inv"].data_ptr())
+            self._buf[key] = b
+        return b
+
+    def text_embeddings(self, tid, tmask) -> torch.Tensor:
+        hs = self.model.llama_decoder.model.hidden_state(tid, tmask, self.layer)
+        return ops.l2norm_rows(ops.readout(hs, tmask, self.readout_fn))
+
+    def forward_backward(self, batch: Dict[str, torch.Tensor], accumulate: bool = False) -> torch.Tensor:
+        """Loss (device scalar, f32 [1]) and adapter gradients into self.g (summed over segments,
+        all-reduce-averaged over ranks).  No host synchronisation."""
+        m, c = self.model, self.c
+        pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
+        tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
+        t_local = self.text_embeddings(tid, tmask)
+        if self.global_negatives:
+            t_all, offset = _gather_text(t_local, self.group)
+        else:
+            t_all, offset = t_local, 0
+        B, T = pid.shape
+        nseg = self.num_segments
+        Bs = B // nseg
+        p_drop = float(m.adapter.dropout.p) if self.train_mode else 0.0
+        wts = _lib.AdapterWeightsC(fc1_w=self.w1.data_ptr(), fc1_b=self.p[1].data_ptr(), fc2_w=self.w2.data_ptr(),
+                                   fc2_b=self.p[3].data_ptr())
+        mode = self.readout_fn
+        for s in range(nseg):
+            sl = slice(s * Bs, (s + 1) * Bs)
+            ids_s, mask_s = pid[sl], pmask[sl]
+            enc = m.esm_encoder.encode(ids_s, mask_s)                                  # [Bs, T, Hp]
+            Hp, M = enc.shape[2], Bs * T
+            b = self._buffers(Bs, T)
+            seed = m.adapter._next_seed() if p_drop > 0 else 0
+            cfg = _lib.AdapterConfigC(input_dim=c.input_dim, intermediate_dim=c.intermediate_dim, output_dim=c.output_dim,
+                                      dropout_p=p_drop, dropout_seed=seed, dtype=ops.dt_of(self.tdt))
+            call("p2t_adapter_forward", C.byref(cfg), C.byref(wts), ptr(enc), Hp, M, ptr(b["y"]), C.byref(b["saved"]), stream())
+            y3 = b["y"].view(Bs, T, -1)
+            rmask = None if self.ones_mask else mask_s
+            pooled_mix = ops.readout(y3, rmask, "mix", D=c.output_dim) if mode in ("std", "mix") else None
+            pooled = pooled_mix if mode == "mix" else ops.readout(y3, rmask, mode, D=c.output_dim)
+            p = ops.l2norm_rows(pooled)
+            labels = torch.arange(sl.start + offset, sl.stop + offset, device=self.dev, dtype=torch.int32)
+            _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, 1.0 / nseg, self.loss,
+                                            accumulate=(s > 0 or accumulate))
+            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, 1.0 / nseg)
+            dpooled = ops.l2norm_rows_backward(pooled, dp)
+            call("p2t_readout_backward", ptr(y3), ops.dt_of(y3), y3.stride(1), ptr(rmask.to(torch.int64).contiguous()) if rmask is not None else None,
+                 Bs, T, c.output_dim, _lib.READOUT[mode], ptr(pooled_mix), ptr(dpooled), ptr(b["dY"]), stream())
+            call("p2t_adapter_backward", C.byref(cfg), C.byref(wts), ptr(enc), Hp, M, C.byref(b["saved"]), ptr(b["dY"]),
+                 ptr(self.g[0]), ptr(self.g[1]), ptr(self.g[2]), ptr(self.g[3]), int(s > 0 or accumulate), ptr(b["ws"]),
+                 b["ws"].numel(), stream())
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG if self.flat_g.is_cuda else dist.ReduceOp.SUM, group=self.group)
+            if not self.flat_g.is_cuda:
+                self.flat_g /= dist.get_world_size(self.group)
+        return self.loss
+
+    def optimizer_step(self):
+        self.step_count += 1
+        ops.clip_adamw_step(self.p, self.g, self.m, self.v, self.step_count, shadows=[self.w1, None, self.w2, None],
+                            scratch=self.scratch, grad_norm_out=self.grad_norm, **self.hp)
+        return self.grad_norm
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        loss = self.forward_backward(batch)
+        self.optimizer_step()
+        return loss
+
+    @torch.no_grad()
+    def evaluate(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Forward-only loss (eval mode, no dropout) on this rank's rows."""
+        saved = self.train_mode
+        self.train_mode = False
+        try:
+            g = self.flat_g.clone()
+            loss = self.forward_backward(batch).clone()
+            self.flat_g.copy_(g)
+        finally:
+            self.train_mode = saved
+        return loss
+
+    @torch.no_grad()
+    def sync_to_module(self):
+        ad = self.model.adapter
+        for src, dst in zip(self.p, (ad.fc1.weight, ad.fc1.bias, ad.fc2.weight, ad.fc2.bias)):
+            dst.copy_(src.to(dst.dtype))

@@ -1,0 +1,565 @@
+"""Host-side mirror of the reference's model classes for the contrastive path.
+
+Same class names, constructor conventions, attribute names (`esm_encoder`, `adapter`,
+`llama_decoder`), forward kwargs / early-exit flags and state-dict keys as the reference's
+models/modeling_esm2llama_instruct.py:45-268, with the arithmetic delegated to libp2t_hip.so:
+
+    Esm2LlamaInstructForCausalLM.forward(protein_input_ids, protein_attention_mask,
+        return_encoder_outputs=True)   -> p2t_esm2_forward            (reference :175-189)
+        return_adapter_outputs=True    -> + p2t_adapter_forward       (reference :191-193)
+    model.llama_decoder.model(input_ids, attention_mask, output_hidden_states=True).hidden_states[k]
+                                       -> p2t_llama_hidden_forward    (scripts/train_contrast.py:292-304)
+
+The modules below are PARAMETER CONTAINERS with HuggingFace key names (so reference checkpoints
+load with load_state_dict) plus an "engine": packed GEMM-layout copies of the weights and the C
+structs that point at them.  No torch op computes anything on this path.  Everything after the
+adapter exit (placeholder scatter, LM head, generate) belongs to the SFT / generation stages and
+is out of scope for this path: those entry points raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+from transformers.modeling_outputs import BaseModelOutputWithPoolingAndCrossAttentions
+
+from . import _lib, ops, specs
+from ._lib import call
+from .configuration import (Esm2LlamaInstructConfig, ModalityAdapterConfig, esm_config_from_spec,
+                            esm_spec_from_config, llama_config_from_spec, llama_spec_from_config)
+from .ops import ptr, round_up, stream
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter trees with HuggingFace key names
+# ---------------------------------------------------------------------------------------------
+def _build_tree(root: nn.Module, tensors, dtype, device, requires_grad=False):
+    for name, shape, _scale, _offset in tensors:
+        *path, leaf = name.split(".")
+        mod = root
+        for p in path:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(leaf, nn.Parameter(torch.empty(shape, dtype=dtype, device=device),
+                                                  requires_grad=requires_grad))
+
+
+def _init_tree(root: nn.Module, std: float = 0.02):
+    """Random init in the spirit of HF `_init_weights`: N(0, std) matrices, zero biases, unit norms."""
+    with torch.no_grad():
+        for name, p in root.named_parameters():
+            if p.dim() == 2:
+                p.normal_(0.0, std)
+            elif name.endswith("bias"):
+                p.zero_()
+            else:
+                p.fill_(1.0)
+
+
+def _fill_synthetic(root: nn.Module, tensors, seed: int, prefix: str = ""):
+    params = dict(root.named_parameters())
+    with torch.no_grad():
+        for name, shape, scale, offset in tensors:
+            p = params[name]
+            assert tuple(p.shape) == tuple(shape), (name, p.shape, shape)
+            ops.fill_hash_(p.data, seed, prefix + name, scale, offset)
+
+
+def _pad_cols(w: torch.Tensor, ld: int, dtype: torch.dtype) -> torch.Tensor:
+    """[N, K] -> [N, ld] (zero padded) in `dtype`; aliases the parameter when nothing changes."""
+    w = w.detach()
+    if w.shape[1] == ld and w.dtype == dtype and w.is_contiguous():
+        return w
+    out = torch.zeros((w.shape[0], ld), dtype=dtype, device=w.device)
+    out[:, : w.shape[1]].copy_(w)
+    return out
+
+
+def _f32(v: torch.Tensor) -> torch.Tensor:
+    v = v.detach()
+    return v if v.dtype == torch.float32 and v.is_contiguous() else v.float().contiguous()
+
+
+class _Workspace:
+    """uint8 workspace tensors cached per key (shape-specialised, reused across calls)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, key, nbytes: int, device) -> torch.Tensor:
+        t = self._cache.get(key)
+        if t is None or t.numel() < nbytes or t.device != device:
+            t = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+            self._cache[key] = t
+        return t
+
+
+# ---------------------------------------------------------------------------------------------
+# ESM2 encoder
+# ---------------------------------------------------------------------------------------------
+class EsmEncoder(nn.Module):
+    """Stands where the reference puts HF `EsmModel(config, add_pooling_layer=False)`
+    (models/modeling_esm2llama_instruct.py:90-93).  forward = HF EsmModel.forward
+    (transformers/models/esm/modeling_esm.py:685-755) on the HIP path."""
+
+    def __init__(self, config, dtype=torch.float32, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.spec = esm_spec_from_config(config)
+        s = self.spec
+        if s.hidden_size % s.num_attention_heads:
+            raise ValueError(f"The hidden size ({s.hidden_size}) is not a multiple of the number of attention heads "
+                             f"({s.num_attention_heads})")
+        _build_tree(self, specs.esm_tensors(s), dtype, device)
+        # HF EsmModel also owns a contact head; kept so state dicts line up (unused on this path)
+        self.add_module("contact_head", nn.Module())
+        self.contact_head.add_module("regression", nn.Module())
+        reg = self.contact_head.regression
+        reg.register_parameter("weight", nn.Parameter(torch.zeros((1, s.num_hidden_layers * s.num_attention_heads),
+                                                                  dtype=dtype, device=device), requires_grad=False))
+        reg.register_parameter("bias", nn.Parameter(torch.zeros((1,), dtype=dtype, device=device), requires_grad=False))
+        self.add_module("rotary_embeddings", nn.Module())
+        d = s.head_dim
+        inv = 1.0 / (s.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))     # modeling_esm.py:127-138
+        self.rotary_embeddings.register_buffer("inv_freq", inv.to(device))
+        _init_tree(self)
+        self._engine = None
+        self._ws = _Workspace()
+
+    @property
+    def dtype(self):
+        return self.embeddings.word_embeddings.weight.dtype
+
+    def invalidate_engine(self):
+        self._engine = None
+
+    def _build_engine(self):
+        s, dt = self.spec, self.dtype
+        H, F = s.hidden_size, s.intermediate_size
+        Hp, Fp = round_up(H, 64), round_up(F, 64)
+        keep, layers = [], (_lib.EsmLayerC * s.num_hidden_layers)()
+        P = dict(self.named_parameters())
+        for i in range(s.num_hidden_layers):
+            p = f"encoder.layer.{i}."
+            qkv_w = _pad_cols(torch.cat([P[p + f"attention.self.{n}.weight"].detach() for n in ("query", "key", "value")], 0), Hp, dt)
+            qkv_b = torch.cat([P[p + f"attention.self.{n}.bias"].detach().float() for n in ("query", "key", "value")], 0).contiguous()
+            t = dict(qkv_w=qkv_w, qkv_b=qkv_b,
+                     o_w=_pad_cols(P[p + "attention.output.dense.weight"], Hp, dt), o_b=_f32(P[p + "attention.output.dense.bias"]),
+                     ln1_w=_f32(P[p + "attention.LayerNorm.weight"]), ln1_b=_f32(P[p + "attention.LayerNorm.bias"]),
+                     fc1_w=_pad_cols(P[p + "intermediate.dense.weight"], Hp, dt), fc1_b=_f32(P[p + "intermediate.dense.bias"]),
+                     fc2_w=_pad_cols(P[p + "output.dense.weight"], Fp, dt), fc2_b=_f32(P[p + "output.dense.bias"]),
+                     ln2_w=_f32(P[p + "LayerNorm.weight"]), ln2_b=_f32(P[p + "LayerNorm.bias"]))
+            keep.append(t)
+            for k, v in t.items():
+                setattr(layers[i], k, v.data_ptr())
+        fw, fb = _f32(P["encoder.emb_layer_norm_after.weight"]), _f32(P["encoder.emb_layer_norm_after.bias"])
+        emb = P["embeddings.word_embeddings.weight"].detach().contiguous()
+        inv = self.rotary_embeddings.inv_freq.detach().float().contiguous()
+        keep += [fw, fb, emb, inv]
+        w = _lib.EsmWeightsC(word_emb=emb.data_ptr(), emb_ln_w=None, emb_ln_b=None,
+                             layers=C.cast(layers, C.POINTER(_lib.EsmLayerC)),
+                             final_ln_w=fw.data_ptr(), final_ln_b=fb.data_ptr(), inv_freq=inv.data_ptr())
+        cfg = _lib.EsmConfigC(n_layers=s.num_hidden_layers, hidden=H, ffn=F, heads=s.num_attention_heads,
+                              head_dim=s.head_dim, vocab=s.vocab_size, pad_id=s.pad_token_id, mask_id=s.mask_token_id,
+                              token_dropout=int(s.token_dropout), emb_layer_norm_before=int(s.emb_layer_norm_before),
+                              layer_norm_eps=s.layer_norm_eps, rope_theta=s.rope_theta, dtype=ops.dt_of(dt))
+        self._engine = dict(cfg=cfg, w=w, layers=layers, keep=keep, Hp=Hp)
+        return self._engine
+
+    def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+        """-> padded last_hidden_state [B, T, Hp] (columns >= hidden are zero; the adapter reads it as is)."""
+        if input_ids is None or input_ids.dim() != 2:
+            raise ValueError("protein_input_ids must be a [batch, seq_len] tensor of token ids")
+        B, T = input_ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if tuple(attention_mask.shape) != (B, T):
+            raise ValueError(f"protein_attention_mask shape {tuple(attention_mask.shape)} != input ids {(B, T)}")
+        e = self._engine or self._build_engine()
+        dev = self.embeddings.word_embeddings.weight.device
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        nbytes = call("p2t_esm2_workspace_bytes", C.byref(e["cfg"]), B, T)
+        ws = self._ws.get((B, T), nbytes, dev)
+        out = torch.empty((B, T, e["Hp"]), dtype=self.dtype, device=dev)
+        call("p2t_esm2_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, ptr(out), e["Hp"],
+             ptr(ws), ws.numel(), stream())
+        return out
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, inputs_embeds=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
+        if inputs_embeds is not None or position_ids is not None or head_mask is not None:
+            raise NotImplementedError("protein_inputs_embeds / protein_position_ids / protein_head_mask are not "
+                                      "supported on the HIP path (the contrastive stage never passes them)")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not available from the fused encoder")
+        h = self.encode(input_ids, attention_mask)[:, :, : self.spec.hidden_size]
+        if return_dict is False:
+            return (h,)
+        return BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=h, pooler_output=None)
+
+
+# ---------------------------------------------------------------------------------------------
+# ModalityAdapter
+# ---------------------------------------------------------------------------------------------
+class _AdapterFn(torch.autograd.Function):
+    """y = normalize(drop(gelu(fc2(drop(gelu(fc1(x))))))) with the hand-written backward
+    (p2t_adapter_forward / p2t_adapter_backward).  Gradients: fc1/fc2 weight and bias only -- the
+    encoder is frozen on this path (scripts/train_contrast.py:186)."""
+
+    @staticmethod
+    def forward(ctx, x_pad, w1, b1, w2, b2, adapter, use_dropout, need_grad):
+        M = x_pad.shape[0]
+        c = adapter.config
+        dt = x_pad.dtype
+        I, O = c.intermediate_dim, c.output_dim
+        ld1, ld2 = round_up(I, 64), round_up(O, 64)
+        dev = x_pad.device
+        p = float(adapter.dropout.p) if use_dropout else 0.0
+        seed = adapter._next_seed() if p > 0.0 else 0
+        cfg = _lib.AdapterConfigC(input_dim=c.input_dim, intermediate_dim=I, output_dim=O, dropout_p=p,
+                                  dropout_seed=seed, dtype=ops.dt_of(dt))
+        K1 = round_up(c.input_dim, 64)
+        w1p, w2p = _pad_cols(w1, K1, dt), _pad_cols(w2, ld1, dt)
+        b1f, b2f = _f32(b1), _f32(b2)
+        wts = _lib.AdapterWeightsC(fc1_w=w1p.data_ptr(), fc1_b=b1f.data_ptr(), fc2_w=w2p.data_ptr(), fc2_b=b2f.data_ptr())
+        h1 = torch.empty((M, ld1), dtype=dt, device=dev)
+        g2 = torch.empty((M, ld2), dtype=dt, device=dev)
+        z1 = torch.empty((M, ld1), dtype=dt, device=dev) if need_grad else None
+        z2 = torch.empty((M, ld2), dtype=dt, device=dev) if need_grad else None
+        inv = torch.empty((M,), dtype=torch.float32, device=dev) if need_grad else None
+        saved = _lib.AdapterSavedC(z1=ops.ptr(z1), h1=h1.data_ptr(), z2=ops.ptr(z2), g2=g2.data_ptr(), inv_norm=ops.ptr(inv))
+        y = torch.empty((M, ld2), dtype=dt, device=dev)
+        call("p2t_adapter_forward", C.byref(cfg), C.byref(wts), ptr(x_pad), x_pad.stride(0), M, ptr(y), C.byref(saved), stream())
+        if need_grad:
+            ctx.cfg, ctx.keep = cfg, (x_pad, w1p, b1f, w2p, b2f, z1, h1, z2, g2, inv)
+            ctx.shapes = (w1.shape, b1.shape, w2.shape, b2.shape, w1.dtype)
+        ctx.need_grad = need_grad
+        return y[:, :O]
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.need_grad:
+            return (None,) * 8
+        x_pad, w1p, b1f, w2p, b2f, z1, h1, z2, g2, inv = ctx.keep
+        cfg = ctx.cfg
+        M, dev = x_pad.shape[0], x_pad.device
+        wts = _lib.AdapterWeightsC(fc1_w=w1p.data_ptr(), fc1_b=b1f.data_ptr(), fc2_w=w2p.data_ptr(), fc2_b=b2f.data_ptr())
+        saved = _lib.AdapterSavedC(z1=z1.data_ptr(), h1=h1.data_ptr(), z2=z2.data_ptr(), g2=g2.data_ptr(), inv_norm=inv.data_ptr())
+        s1, sb1, s2, sb2, pdt = ctx.shapes
+        g = [torch.empty(s, dtype=torch.float32, device=dev) for s in (s1, sb1, s2, sb2)]
+        nbytes = call("p2t_adapter_backward_workspace_bytes", C.byref(cfg), M)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        dyf = dy.float().contiguous() if (dy.dtype != torch.float32 or not dy.is_contiguous()) else dy
+        call("p2t_adapter_backward", C.byref(cfg), C.byref(wts), ptr(x_pad), x_pad.stride(0), M, C.byref(saved), ptr(dyf),
+             ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), 0, ptr(ws), ws.numel(), stream())
+        g = [t if pdt == torch.float32 else ops.cast(t, pdt) for t in g]
+        return None, g[0], g[1], g[2], g[3], None, None, None
+
+
+class ModalityAdapter(nn.Module):
+    """2-layer adapter, reference models/modeling_esm2llama_instruct.py:45-68.  `ln1`/`ln2` are
+    constructed (and saved) but unused, exactly as upstream (":56-57 DEPRECATED")."""
+    config_class = ModalityAdapterConfig
+
+    def __init__(self, config: ModalityAdapterConfig, dtype=torch.float32, device="cuda"):
+        super().__init__()
+        self.config = config
+        kw = dict(dtype=dtype, device=device)
+        self.fc1 = nn.Linear(config.input_dim, config.intermediate_dim, **kw)
+        self.fc2 = nn.Linear(config.intermediate_dim, config.output_dim, **kw)
+        self.activation = nn.GELU()
+        self.dropout = nn.Dropout(p=config.dropout_rate)
+        self.ln1 = nn.LayerNorm(config.intermediate_dim, **kw)
+        self.ln2 = nn.LayerNorm(config.output_dim, **kw)
+        with torch.no_grad():
+            for lin in (self.fc1, self.fc2):
+                lin.weight.normal_(0.0, 0.02)
+                lin.bias.zero_()
+        self._seed_state = 0x5DEECE66D
+        self._calls = 0
+
+    def _next_seed(self) -> int:
+        self._calls += 1
+        return (self._seed_state + 0x9E3779B97F4A7C15 * self._calls) & ((1 << 64) - 1)
+
+    def manual_seed(self, seed: int):
+        self._seed_state, self._calls = int(seed) & ((1 << 64) - 1), 0
+
+    def forward_padded(self, x_pad: torch.Tensor) -> torch.Tensor:
+        """x_pad: [M, ld >= round_up(input_dim, 64)] with zero padding -> [M, output_dim]."""
+        params = (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _AdapterFn.apply(x_pad, *params, self, bool(self.training), need_grad)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        c = self.config
+        if hidden_states.shape[-1] != c.input_dim:
+            raise ValueError(f"adapter input has {hidden_states.shape[-1]} features, config.input_dim={c.input_dim}")
+        lead = hidden_states.shape[:-1]
+        x = hidden_states.reshape(-1, c.input_dim)
+        K1 = round_up(c.input_dim, 64)
+        wd = self.fc1.weight.dtype
+        if x.dtype != wd or x.shape[1] != K1 or x.stride(1) != 1 or x.stride(0) < K1:
+            xp = torch.zeros((x.shape[0], K1), dtype=wd, device=self.fc1.weight.device)
+            xp[:, : c.input_dim].copy_(x)
+            x = xp
+        return self.forward_padded(x).reshape(*lead, c.output_dim)
+
+
+# ---------------------------------------------------------------------------------------------
+# Llama text tower
+# ---------------------------------------------------------------------------------------------
+class LazyHiddenStates:
+    """`outputs.hidden_states` of the text tower: indexing [k] runs the decoder up to layer k only
+    (the reference materialises all L+1 states and reads index 16, train_contrast.py:294-304)."""
+
+    def __init__(self, model: "LlamaTextModel", ids, mask):
+        self._m, self._ids, self._mask, self._cache = model, ids, mask, {}
+
+    def __len__(self):
+        return self._m.spec.num_hidden_layers + 1
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return tuple(self[i] for i in range(*k.indices(len(self))))
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(f"hidden_states index {k} out of range for {len(self) - 1} layers")
+        if k not in self._cache:
+            self._cache[k] = self._m.hidden_state(self._ids, self._mask, k)
+        return self._cache[k]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class LlamaTextOutput:
+    def __init__(self, hidden_states: LazyHiddenStates):
+        self.hidden_states = hidden_states
+        self.past_key_values = None
+
+    @property
+    def last_hidden_state(self):
+        return self.hidden_states[-1]
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state, self.hidden_states)[i]
+
+
+class LlamaTextModel(nn.Module):
+    """Stands where HF `LlamaModel` sits (`llama_decoder.model`); forward restates
+    transformers/models/llama/modeling_llama.py:367-417 up to the requested hidden state."""
+
+    def __init__(self, spec: specs.LlamaSpec, dtype, device):
+        super().__init__()
+        self.spec = spec
+        self._engine, self._ws = None, _Workspace()
+
+    @property
+    def dtype(self):
+        return self.embed_tokens.weight.dtype
+
+    def invalidate_engine(self):
+        self._engine = None
+
+    def _build_engine(self, n_layers: int):
+        s, dt = self.spec, self.dtype
+        H, F, d = s.hidden_size, s.intermediate_size, s.head_dim
+        if F % 16:
+            raise ValueError("Llama intermediate_size must be a multiple of 16")
+        Hp, Fp, QO = round_up(H, 64), round_up(F, 64), round_up(s.num_attention_heads * d, 64)
+        keep, layers = [], (_lib.LlamaLayerC * max(n_layers, 1))()
+        P = dict(self.named_parameters())
+        for i in range(n_layers):
+            p = f"layers.{i}."
+            qkv = torch.cat([P[p + f"self_attn.{n}_proj.weight"].detach() for n in ("q", "k", "v")], 0)
+            gate, up = P[p + "mlp.gate_proj.weight"].detach(), P[p + "mlp.up_proj.weight"].detach()
+            gu = torch.stack([gate.view(F // 16, 16, H), up.view(F // 16, 16, H)], 1).reshape(2 * F, H)
+            t = dict(qkv_w=_pad_cols(qkv, Hp, dt), o_w=_pad_cols(P[p + "self_attn.o_proj.weight"], QO, dt),
+                     gu_w=_pad_cols(gu, Hp, dt), down_w=_pad_cols(P[p + "mlp.down_proj.weight"], Fp, dt),
+                     ln1_w=_f32(P[p + "input_layernorm.weight"]), ln2_w=_f32(P[p + "post_attention_layernorm.weight"]))
+            keep.append(t)
+            for k, v in t.items():
+                setattr(layers[i], k, v.data_ptr())
+        emb, fn = P["embed_tokens.weight"].detach().contiguous(), _f32(P["norm.weight"])
+        inv = self._inv_freq().to(emb.device)
+        keep += [emb, fn, inv]
+        w = _lib.LlamaWeightsC(embed=emb.data_ptr(), layers=C.cast(layers, C.POINTER(_lib.LlamaLayerC)),
+                               final_norm_w=fn.data_ptr(), inv_freq=inv.data_ptr())
+        cfg = _lib.LlamaConfigC(n_layers=s.num_hidden_layers, hidden=H, ffn=F, heads=s.num_attention_heads,
+                                kv_heads=s.num_key_value_heads, head_dim=d, vocab=s.vocab_size,
+                                rms_norm_eps=s.rms_norm_eps, rope_theta=s.rope_theta,
+                                rope_llama3=int(s.rope_type == "llama3"), rope_factor=s.rope_factor,
+                                rope_low_freq_factor=s.rope_low_freq_factor, rope_high_freq_factor=s.rope_high_freq_factor,
+                                rope_original_max_pos=s.rope_original_max_position_embeddings, dtype=ops.dt_of(dt))
+        self._engine = dict(cfg=cfg, w=w, layers=layers, keep=keep, n=n_layers)
+        return self._engine
+
+    def _inv_freq(self) -> torch.Tensor:
+        """fp32 inv_freq exactly as transformers computes it (modeling_rope_utils.py:580-662)."""
+        s = self.spec
+        d = s.head_dim
+        inv = 1.0 / (s.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).to(dtype=torch.float) / d))
+        if s.rope_type == "llama3":
+            old = s.rope_original_max_position_embeddings
+            low_wl, high_wl = old / s.rope_low_freq_factor, old / s.rope_high_freq_factor
+            wavelen = 2 * math.pi / inv
+            inv_l = torch.where(wavelen > low_wl, inv / s.rope_factor, inv)
+            smooth = (old / wavelen - s.rope_low_freq_factor) / (s.rope_high_freq_factor - s.rope_low_freq_factor)
+            smoothed = (1 - smooth) * inv_l / s.rope_factor + smooth * inv_l
+            medium = ~(wavelen < high_wl) * ~(wavelen > low_wl)
+            inv = torch.where(medium, smoothed, inv_l)
+        return inv.float().contiguous()
+
+    def hidden_state(self, input_ids, attention_mask, k: int) -> torch.Tensor:
+        """hidden_states[k] as f32 [B, T, hidden] (k = n_layers -> post final RMSNorm)."""
+        if input_ids is None or input_ids.dim() != 2:
+            raise ValueError("input_ids must be a [batch, seq_len] tensor of token ids")
+        B, T = input_ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if tuple(attention_mask.shape) != (B, T):
+            raise ValueError(f"attention_mask shape {tuple(attention_mask.shape)} != input ids {(B, T)}")
+        e = self._engine
+        if e is None or e["n"] < k:
+            e = self._build_engine(k)
+        dev = self.embed_tokens.weight.device
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        nbytes = call("p2t_llama_workspace_bytes", C.byref(e["cfg"]), B, T)
+        ws = self._ws.get((B, T), nbytes, dev)
+        out = torch.empty((B, T, self.spec.hidden_size), dtype=torch.float32, device=dev)
+        call("p2t_llama_hidden_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, int(k), ptr(out),
+             ptr(ws), ws.numel(), stream())
+        return out
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
+        if inputs_embeds is not None or position_ids is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("inputs_embeds / position_ids / KV cache belong to the SFT and generation stages, "
+                                      "which are out of scope of the contrastive path")
+        if output_attentions:
+            raise NotImplementedError("output_attentions is not available from the fused decoder")
+        return LlamaTextOutput(LazyHiddenStates(self, input_ids, attention_mask))
+
+
+class LlamaDecoder(nn.Module):
+    """Stands where the reference puts HF `LlamaForCausalLM` (attribute `llama_decoder`): owns
+    `.model` (text tower) and `.lm_head`.  The causal-LM forward / generate are SFT-stage features."""
+
+    def __init__(self, config, dtype=torch.float32, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.spec = llama_spec_from_config(config)
+        s = self.spec
+        self.model = LlamaTextModel(s, dtype, device)
+        tens = [(n[len("model."):], sh, sc, of) for n, sh, sc, of in specs.llama_tensors(s, lm_head=False)]
+        _build_tree(self.model, tens, dtype, device)
+        self.add_module("lm_head", nn.Module())
+        if s.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+        else:
+            self.lm_head.register_parameter("weight", nn.Parameter(
+                torch.empty((s.vocab_size, s.hidden_size), dtype=dtype, device=device), requires_grad=False))
+        _init_tree(self)
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("LlamaForCausalLM.forward (LM head + cross-entropy) is the SFT stage "
+                                  "(scripts/train_instruct.py), out of scope for the contrastive path; use "
+                                  "llama_decoder.model(...).hidden_states[k]")
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError("generation is out of scope for the contrastive path")
+
+
+# ---------------------------------------------------------------------------------------------
+# the assembled model
+# ---------------------------------------------------------------------------------------------
+class Esm2LlamaInstructForCausalLM(nn.Module):
+    """Esm2LlamaInstructForCausalLM = ESM2 encoder + ModalityAdapter + Llama decoder
+    (reference models/modeling_esm2llama_instruct.py:71-268).  Initialise with either a
+    configuration OR all three components; `kwargs` override standalone config attributes."""
+    config_class = Esm2LlamaInstructConfig
+
+    def __init__(self, config: Optional[Esm2LlamaInstructConfig] = None, esm_encoder: Optional[EsmEncoder] = None,
+                 adapter: Optional[ModalityAdapter] = None, llama_decoder: Optional[LlamaDecoder] = None,
+                 dtype=torch.float32, device="cuda", **kwargs):
+        super().__init__()
+        if config is not None:                    # components ignored if config is provided (reference :88-95)
+            self.config = config
+            self.esm_encoder = EsmEncoder(config.esm_config, dtype, device)
+            self.adapter = ModalityAdapter(config.adapter_config, dtype, device)
+            self.llama_decoder = LlamaDecoder(config.llama_config, dtype, device)
+        else:
+            if esm_encoder is None or adapter is None or llama_decoder is None:
+                raise ValueError("pass either `config` or all of esm_encoder, adapter and llama_decoder")
+            self.config = Esm2LlamaInstructConfig(esm_config=esm_encoder.config, adapter_config=adapter.config,
+                                                  llama_config=llama_decoder.config, **kwargs)
+            self.esm_encoder, self.adapter, self.llama_decoder = esm_encoder, adapter, llama_decoder
+
+    # ---- synthetic construction (bench / tests: no checkpoints exist offline) ----
+    @classmethod
+    def from_specs(cls, esm: specs.EsmSpec, llama: specs.LlamaSpec, adapter: specs.AdapterSpec, dtype=torch.bfloat16,
+                   device="cuda", seed: Optional[int] = 0, adapter_dtype=None):
+        model = cls(esm_encoder=EsmEncoder(esm_config_from_spec(esm), dtype, device),
+                    adapter=ModalityAdapter(ModalityAdapterConfig(adapter.input_dim, adapter.intermediate_dim,
+                                                                  adapter.output_dim, adapter.dropout_rate),
+                                            adapter_dtype or dtype, device),
+                    llama_decoder=LlamaDecoder(llama_config_from_spec(llama), dtype, device))
+        if seed is not None:
+            model.fill_synthetic(seed)
+        return model
+
+    def fill_synthetic(self, seed: int = 0):
+        """Weights from the counter-hash generator (p2t_hip.synth), identical to what the oracle and
+        the golden-vector generator materialise for the same seed."""
+        _fill_synthetic(self.esm_encoder, specs.esm_tensors(self.esm_encoder.spec), seed, "esm_encoder.")
+        _fill_synthetic(self.adapter, specs.adapter_tensors(self.adapter.config.to_spec()), seed, "adapter.")
+        ls = self.llama_decoder.spec
+        _fill_synthetic(self.llama_decoder, specs.llama_tensors(ls), seed, "llama_decoder.")
+        self.esm_encoder.invalidate_engine()
+        self.llama_decoder.model.invalidate_engine()
+        return self
+
+    def prepare_decoder_inputs(self, *args, **kwargs):
+        raise NotImplementedError("placeholder replacement feeds the SFT / generation stages "
+                                  "(reference :108-139), out of scope for the contrastive path")
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, labels=None,
+                protein_input_ids=None, protein_attention_mask=None, protein_position_ids=None, protein_head_mask=None,
+                protein_inputs_embeds=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, return_encoder_outputs: bool = False, return_adapter_outputs: bool = False,
+                return_decoder_inputs: bool = False, cache_position=None):
+        if protein_position_ids is not None or protein_head_mask is not None or protein_inputs_embeds is not None:
+            raise NotImplementedError("protein_position_ids / protein_head_mask / protein_inputs_embeds are not supported")
+        if return_encoder_outputs:                 # reference :175-189
+            return self.esm_encoder(input_ids=protein_input_ids, attention_mask=protein_attention_mask,
+                                    output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                                    return_dict=return_dict)
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not available from the fused encoder")
+        enc = self.esm_encoder.encode(protein_input_ids, protein_attention_mask)      # [B, T, Hp], zero padded
+        B, T, Hp = enc.shape
+        adapter_output = self.adapter.forward_padded(enc.view(B * T, Hp)).reshape(B, T, -1)   # reference :191
+        if return_adapter_outputs:                 # reference :192-193
+            return adapter_output, protein_attention_mask
+        raise NotImplementedError("the decoder half of forward (placeholder scatter + Llama LM loss, reference :195-215) "
+                                  "is the SFT stage and out of scope; use return_encoder_outputs / return_adapter_outputs")
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError("generation is out of scope for the contrastive path")
+
+    def gradient_checkpointing_enable(self):
+        """No-op: the towers are frozen and run without autograd on this path (reference :253-261)."""
+
+    def gradient_checkpointing_disable(self):
+        """No-op (reference :263-268)."""

@@ -1,0 +1,236 @@
+"""Tensor-level wrappers over the C ABI (torch is only the allocator and the stream provider).
+
+Each function checks shapes/dtypes on the host (ValueError, mirroring the reference's own argument
+checks, e.g. models/esmc_qwen_arc.py:137-141) before a kernel sees a pointer, then enqueues on the
+current HIP stream.  Nothing here computes with torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, synth
+from ._lib import BF16, F32, call
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt_of(t: torch.Tensor | torch.dtype) -> int:
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    if d not in _DT:
+        raise ValueError(f"unsupported dtype {d}: the HIP path stores float32 or bfloat16")
+    return _DT[d]
+
+
+def ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("tensor must live on the GPU (there is no CPU path)")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _chk(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+# ---------------------------------------------------------------------------------------------
+def fill_hash_(t: torch.Tensor, seed: int, name: str, scale: float, offset: float = 0.0) -> torch.Tensor:
+    """In-place synthetic fill, bit-identical to synth.uniform_f32(seed, name, t.shape, scale, offset)."""
+    _chk(t.is_contiguous(), "fill_hash_: tensor must be contiguous")
+    if scale == 0.0:
+        t.fill_(offset)
+        return t
+    add, xor = synth.stream_key(seed, name)
+    call("p2t_fill_hash", ptr(t), t.numel(), add, xor, float(synth.scale_f32(scale)), float(offset), dt_of(t), stream())
+    return t
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    out = torch.empty_like(src, dtype=dtype)
+    call("p2t_cast", ptr(src.contiguous()), dt_of(src), ptr(out), dt_of(out), src.numel(), stream())
+    return out
+
+
+def transpose(src: torch.Tensor, ld_dst: int | None = None) -> torch.Tensor:
+    _chk(src.dim() == 2 and src.stride(1) == 1, "transpose: 2-D row-major input")
+    rows, cols = src.shape
+    ld_dst = round_up(rows, 64) if ld_dst is None else ld_dst
+    out = torch.empty((cols, ld_dst), dtype=src.dtype, device=src.device)
+    call("p2t_transpose", ptr(src), rows, cols, src.stride(0), ptr(out), ld_dst, dt_of(src), stream())
+    return out
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *, n: int | None = None,
+            k: int | None = None, epilogue: int = _lib.EPI_STORE, out: torch.Tensor | None = None,
+            out_dtype: torch.dtype | None = None, z: torch.Tensor | None = None, accumulate: bool = False,
+            use_mfma: int = -1) -> torch.Tensor:
+    """out = epilogue(a[:, :k] @ w[:n, :k].T).  a: [M, lda], w: [>=n, ldw] (row strides = storage width)."""
+    _chk(a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1, "gemm_nt: 2-D row-major operands")
+    _chk(a.dtype == w.dtype, "gemm_nt: operand dtypes differ")
+    M = a.shape[0]
+    n = w.shape[0] if n is None else n
+    k = min(a.shape[1], w.shape[1]) if k is None else k
+    n_out = n // 2 if epilogue == _lib.EPI_SWIGLU else n
+    if out is None:
+        od = torch.float32 if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else (out_dtype or a.dtype)
+        ldc = n_out if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else round_up(n_out, 64)
+        out = torch.empty((M, ldc), dtype=od, device=a.device)
+    call("p2t_gemm_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), ptr(z), M, n, k,
+         dt_of(a), dt_of(out), epilogue, int(accumulate), use_mfma, stream())
+    return out
+
+
+def layernorm(x, w, b, eps, out_dtype=torch.float32, ld_out=None):
+    _chk(x.dtype == torch.float32 and x.dim() == 2, "layernorm: x must be f32 [rows, cols]")
+    rows, cols = x.shape
+    ld = round_up(cols, 64) if ld_out is None else ld_out
+    y = torch.empty((rows, ld), dtype=out_dtype, device=x.device)
+    call("p2t_layernorm", ptr(x), x.stride(0), ptr(w), ptr(b), float(eps), ptr(y), ld, rows, cols, dt_of(y), stream())
+    return y
+
+
+def rmsnorm(x, w, eps, out_dtype=torch.float32, ld_out=None):
+    _chk(x.dtype == torch.float32 and x.dim() == 2, "rmsnorm: x must be f32 [rows, cols]")
+    rows, cols = x.shape
+    ld = round_up(cols, 64) if ld_out is None else ld_out
+    y = torch.empty((rows, ld), dtype=out_dtype, device=x.device)
+    call("p2t_rmsnorm", ptr(x), x.stride(0), ptr(w), float(eps), ptr(y), ld, rows, cols, dt_of(y), stream())
+    return y
+
+
+def head_dim_padded(d: int) -> int:
+    return 32 if d <= 32 else (64 if d <= 64 else 128)
+
+
+def mask_prepare(mask: torch.Tensor, ids: torch.Tensor | None = None, mask_id: int = -1, token_dropout: bool = False):
+    B, T = mask.shape
+    key_mask = torch.empty((B, T), dtype=torch.uint8, device=mask.device)
+    kv_info = torch.empty((2 * B,), dtype=torch.int32, device=mask.device)
+    emb_scale = torch.empty((2 * B,), dtype=torch.float32, device=mask.device) if ids is not None else None
+    call("p2t_mask_prepare", ptr(ids), ptr(mask.contiguous()), B, T, mask_id, int(token_dropout), ptr(key_mask),
+         ptr(kv_info), ptr(emb_scale), stream())
+    return key_mask, kv_info, emb_scale
+
+
+def qkv_post(qkv: torch.Tensor, inv_freq: torch.Tensor, B: int, T: int, nh: int, nkv: int, d: int, q_scale: float):
+    dp, tp = head_dim_padded(d), round_up(T, 64)
+    dev, dty = qkv.device, qkv.dtype
+    q = torch.empty((B, nh, T, dp), dtype=dty, device=dev)
+    k = torch.empty((B, nkv, T, dp), dtype=dty, device=dev)
+    vt = torch.empty((B, nkv, dp, tp), dtype=dty, device=dev)
+    cs = torch.empty((T, d), dtype=torch.float32, device=dev)
+    call("p2t_qkv_post", ptr(qkv), qkv.stride(0), ptr(inv_freq), ptr(cs), ptr(q), ptr(k), ptr(vt), B, T, nh, nkv, d, dp, tp,
+         float(q_scale), dt_of(qkv), stream())
+    return q, k, vt
+
+
+def attention(q, k, vt, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1):
+    B, nh, T, dp = q.shape
+    nkv, tp = k.shape[1], vt.shape[3]
+    ld = round_up(nh * d, 64)
+    out = torch.empty((B * T, ld), dtype=q.dtype, device=q.device)
+    call("p2t_attention", ptr(q), ptr(k), ptr(vt), ptr(key_mask), ptr(kv_info), ptr(out), ld, B, T, nh, nkv, d, dp, tp,
+         float(scale), int(causal), dt_of(q), use_mfma, stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def readout(emb: torch.Tensor, mask: torch.Tensor | None, mode: str, D: int | None = None) -> torch.Tensor:
+    """readout_embeddings (scripts/train_contrast.py:198-248): emb [B, T, >=D] -> f32 [B, D] or [B, 2D]."""
+    _chk(mode in _lib.READOUT, f"readout_fn must be one of {list(_lib.READOUT)}, got {mode!r}")
+    _chk(emb.dim() == 3 and emb.stride(2) == 1 and emb.stride(0) == emb.shape[1] * emb.stride(1), "readout: [B, T, ld] layout")
+    B, T = emb.shape[:2]
+    D = emb.shape[2] if D is None else D
+    if mask is not None:
+        _chk(tuple(mask.shape) == (B, T), "readout: attention_mask must be [B, T]")
+        mask = mask.to(torch.int64).contiguous()
+    out = torch.empty((B, 2 * D if mode == "mix" else D), dtype=torch.float32, device=emb.device)
+    call("p2t_readout", ptr(emb), dt_of(emb), emb.stride(1), ptr(mask), B, T, D, _lib.READOUT[mode], ptr(out), stream())
+    return out
+
+
+def readout_backward(emb, mask, mode: str, pooled_mix, d_out, D: int | None = None) -> torch.Tensor:
+    B, T = emb.shape[:2]
+    D = emb.shape[2] if D is None else D
+    if mask is not None:
+        mask = mask.to(torch.int64).contiguous()
+    d_emb = torch.empty((B, T, D), dtype=torch.float32, device=emb.device)
+    call("p2t_readout_backward", ptr(emb), dt_of(emb), emb.stride(1), ptr(mask), B, T, D, _lib.READOUT[mode],
+         ptr(pooled_mix), ptr(d_out.contiguous()), ptr(d_emb), stream())
+    return d_emb
+
+
+def l2norm_rows(x: torch.Tensor, eps: float = 1e-12):
+    _chk(x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous(), "l2norm_rows: contiguous f32 [rows, cols]")
+    y = torch.empty_like(x)
+    call("p2t_l2norm_rows", ptr(x), ptr(y), None, x.shape[0], x.shape[1], float(eps), stream())
+    return y
+
+
+def l2norm_rows_backward(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-12):
+    dx = torch.empty_like(x)
+    call("p2t_l2norm_rows_backward", ptr(x), ptr(dy.contiguous()), ptr(dx), x.shape[0], x.shape[1], float(eps), stream())
+    return dx
+
+
+def infonce_forward(seg, batch, labels, temperature=0.05, weight=1.0, loss_out=None, accumulate=False):
+    """Returns (loss[1] f32, logits [S, N]).  loss (+)= weight * mean_i CE(seg_i batch^T / tau, labels_i)."""
+    _chk(seg.dtype == torch.float32 and batch.dtype == torch.float32, "infonce: f32 embeddings")
+    _chk(seg.dim() == 2 and batch.dim() == 2 and seg.shape[1] == batch.shape[1], "infonce: [S, D] x [N, D]")
+    S, D = seg.shape
+    N = batch.shape[0]
+    _chk(labels.numel() == S, "infonce: one label per segment row")
+    labels = labels.to(torch.int32).contiguous()
+    if loss_out is None:
+        loss_out = torch.zeros((1,), dtype=torch.float32, device=seg.device)
+        accumulate = False
+    logits = torch.empty((S, N), dtype=torch.float32, device=seg.device)
+    row_loss = torch.empty((S,), dtype=torch.float32, device=seg.device)
+    call("p2t_infonce_forward", ptr(seg.contiguous()), ptr(batch.contiguous()), ptr(labels), S, N, D, float(temperature),
+         float(weight), int(accumulate), ptr(loss_out), ptr(logits), ptr(row_loss), stream())
+    return loss_out, logits
+
+
+def infonce_backward(batch, labels, logits, temperature=0.05, weight=1.0):
+    S, N = logits.shape
+    D = batch.shape[1]
+    labels = labels.to(torch.int32).contiguous()
+    d_seg = torch.empty((S, D), dtype=torch.float32, device=batch.device)
+    call("p2t_infonce_backward", ptr(batch.contiguous()), ptr(labels), ptr(logits), S, N, D, float(temperature), float(weight),
+         ptr(d_seg), stream())
+    return d_seg
+
+
+def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step: int, *, lr=2e-4, betas=(0.9, 0.999), eps=1e-6,
+                    weight_decay=0.01, max_norm=math.inf, shadows=None, scratch=None, grad_norm_out=None):
+    """clip_grad_norm_ + AdamW.step on f32 tensors (train_contrast.py:453-465).  shadows[i]: optional 2-D
+    tensor (bf16/f32, row stride >= cols) refreshed with the new value of the 2-D params[i]."""
+    n = len(params)
+    dev = params[0].device
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])
+    numel = (C.c_int64 * n)(*[p.numel() for p in params])
+    shadows = shadows or [None] * n
+    cols = (C.c_int64 * n)(*[(p.shape[-1] if p.dim() == 2 else p.numel()) for p in params])
+    lds = (C.c_int64 * n)(*[(s.stride(0) if s is not None else 1) for s in shadows])
+    sdt = next((dt_of(s) for s in shadows if s is not None), F32)
+    if scratch is None:
+        scratch = torch.empty((256 * n,), dtype=torch.float32, device=dev)
+    if grad_norm_out is None:
+        grad_norm_out = torch.empty((1,), dtype=torch.float32, device=dev)
+    mn = 0.0 if (max_norm is None or math.isinf(max_norm)) else float(max_norm)
+    call("p2t_clip_adamw_step", n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, arr(shadows), cols, lds,
+         sdt, int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), mn,
+         ptr(grad_norm_out), ptr(scratch), stream())
+    return grad_norm_out

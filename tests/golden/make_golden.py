@@ -192,9 +192,14 @@ def run_case(ref, name, esm, llama, ad, B, T_p, T_t, p_lens, t_lens, layers, id_
             (acc / nseg).backward(retain_graph=True)
             for n, prm in model.adapter.named_parameters():
                 if prm.grad is not None:
-                    out[f"grad_seg{nseg}_{n}"] = prm.grad.numpy().copy()
+                    gnp = prm.grad.numpy()
+                    if not store_hidden and gnp.ndim == 2:     # big model: strided sample + exact norm
+                        out[f"gradnorm_seg{nseg}_{n}"] = np.float32(np.linalg.norm(gnp.astype(np.float64)))
+                        gnp = gnp[::7, ::5]
+                    out[f"grad_seg{nseg}_{n}"] = gnp.copy()
                 else:
                     assert n.startswith("ln"), n      # ln1/ln2 are unused
+    if grads and store_hidden:
         # one clip + AdamW step with the reference's optimizer settings (train_contrast.py:621-626)
         model.adapter.zero_grad()
         p_mix = F.normalize(tc.readout_embeddings(ad_out, pmask_t, "mix"), p=2, dim=-1)

@@ -1,0 +1,302 @@
+"""GPU parity, kernel level: every HIP kernel through the C ABI against the numpy oracle on the same
+seeded inputs.  fp32 kernels: fp32 round-off tolerances.  bf16 MFMA kernels: compared with the oracle
+evaluated on the SAME bf16-rounded operands (fp32 accumulate), so the tolerance only covers the
+accumulation order and the final bf16 rounding of the output."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import p2t_oracle as O
+from gpu_util import bf16r, dev, maxabs, rel, rnd, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+EPI_STORE, EPI_GELU, EPI_RESID, EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD = range(6)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from p2t_hip import ops as _ops
+    return _ops
+
+
+# ---------------------------------------------------------------------------------------------
+def test_fill_hash_bit_exact(ops):
+    from p2t_hip import synth
+    for n, scale, offset in ((1000003, 0.37, 0.0), (4096, 0.1, 1.0), (7, 2.0, -0.5)):
+        ref = synth.uniform_f32(11, "t.fill", (n,), scale, offset)
+        t = torch.empty((n,), dtype=torch.float32, device=dev())
+        ops.fill_hash_(t, 11, "t.fill", scale, offset)
+        assert np.array_equal(to_np(t), ref)
+        tb = torch.empty((n,), dtype=torch.bfloat16, device=dev())
+        ops.fill_hash_(tb, 11, "t.fill", scale, offset)
+        assert np.array_equal(to_np(tb), synth.bf16_round(ref))
+
+
+def test_cast_transpose(ops):
+    a = rnd(1, "ct.a", (130, 70), 3.0)
+    t = to_dev(a)
+    assert np.array_equal(to_np(ops.cast(t, torch.bfloat16)), bf16r(a))
+    tt = ops.transpose(t)                       # [70, 192], zero padded
+    got = to_np(tt)
+    assert np.array_equal(got[:, :130], a.T) and not got[:, 130:].any()
+    tb = ops.transpose(to_dev(a, torch.bfloat16))
+    assert np.array_equal(to_np(tb)[:, :130], bf16r(a).T)
+
+
+def _gemm_ref(a, w, bias, epi, resid=None, z=None):
+    acc = a.astype(np.float32) @ w.astype(np.float32).T
+    if epi == EPI_SWIGLU:
+        F = w.shape[0] // 2
+        v = acc.reshape(acc.shape[0], F // 16, 2, 16)
+        g, u = v[:, :, 0, :].reshape(-1, F), v[:, :, 1, :].reshape(-1, F)
+        return (g / (1 + np.exp(-g))) * u
+    if bias is not None:
+        acc = acc + bias
+    if epi == EPI_GELU:
+        return O.gelu_erf(acc)
+    if epi == EPI_RESID:
+        return resid + acc
+    if epi == EPI_GELU_BWD:
+        return acc * O.gelu_erf_grad(z)
+    return acc
+
+
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_GELU, EPI_RESID, EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD])
+@pytest.mark.parametrize("shape", [(70, 96, 52), (257, 320, 128)])
+def test_gemm_fp32(ops, epi, shape):
+    M, N, K = shape
+    a, w = rnd(2, "g.a", (M, K), 1.0), rnd(2, "g.w", (N, K), 0.5)
+    bias = None if epi in (EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD) else rnd(2, "g.b", (N,), 0.3)
+    n_out = N // 2 if epi == EPI_SWIGLU else N
+    ld = ops.round_up(n_out, 64)
+    resid = rnd(2, "g.r", (M, N), 1.0)
+    zin = rnd(2, "g.z", (M, ld), 1.5)
+    out = z = None
+    if epi == EPI_RESID:
+        out = to_dev(resid)
+    if epi == EPI_GELU_BWD:
+        z = to_dev(zin)
+    if epi == EPI_GELU:
+        z = torch.full((M, ld), 7.0, dtype=torch.float32, device=dev())
+    got = ops.gemm_nt(to_dev(a), to_dev(w), to_dev(bias) if bias is not None else None, epilogue=epi, out=out, z=z)
+    ref = _gemm_ref(a, w, bias, epi, resid, zin[:, :N])
+    g = to_np(got)
+    assert rel(g[:, :n_out], ref) < 2e-6
+    if g.shape[1] > n_out:
+        assert not g[:, n_out:].any()                       # zero K-padding for the next GEMM
+    if epi == EPI_GELU:
+        assert rel(to_np(z)[:, :N], a @ w.T + bias) < 2e-6
+
+
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_GELU, EPI_RESID, EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD])
+@pytest.mark.parametrize("shape", [(300, 320, 320), (1000, 96, 64), (4096, 4096, 128), (2048, 1184, 192)])
+def test_gemm_mfma_bf16(ops, epi, shape):
+    M, N, K = shape
+    if epi == EPI_SWIGLU and N % 32:
+        pytest.skip("swiglu needs N % 32 == 0")
+    a, w = bf16r(rnd(3, "m.a", (M, K), 1.0)), bf16r(rnd(3, "m.w", (N, K), 0.5))
+    bias = None if epi in (EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD) else rnd(3, "m.b", (N,), 0.3)
+    n_out = N // 2 if epi == EPI_SWIGLU else N
+    ld = ops.round_up(n_out, 64)
+    resid = rnd(3, "m.r", (M, N), 1.0)
+    zin = bf16r(rnd(3, "m.z", (M, ld), 1.5))
+    out = z = None
+    if epi == EPI_RESID:
+        out = to_dev(resid)
+    if epi == EPI_GELU_BWD:
+        z = to_dev(zin, torch.bfloat16)
+    if epi == EPI_GELU:
+        z = torch.full((M, ld), 7.0, dtype=torch.bfloat16, device=dev())
+    got = ops.gemm_nt(to_dev(a, torch.bfloat16), to_dev(w, torch.bfloat16), to_dev(bias) if bias is not None else None,
+                      epilogue=epi, out=out, z=z, use_mfma=1)
+    ref = _gemm_ref(a, w, bias, epi, resid, zin[:, :N])
+    g = to_np(got)
+    exact_out = epi in (EPI_RESID, EPI_STORE_F32)
+    assert rel(g[:, :n_out], ref) < (3e-6 if exact_out else 3e-3)          # bf16 output rounding = 2^-9
+    assert maxabs(g[:, :n_out], ref) < (1e-4 if exact_out else 0.02 * max(1.0, float(np.abs(ref).max())))
+    if g.shape[1] > n_out:
+        assert not g[:, n_out:].any()
+
+
+def test_gemm_mfma_matches_fma_kernel(ops):
+    """Same bf16 inputs through both kernels (the fp32-FMA kernel is the exact one)."""
+    M, N, K = 1500, 640, 448
+    a, w = to_dev(rnd(4, "x.a", (M, K)), torch.bfloat16), to_dev(rnd(4, "x.w", (N, K), 0.2), torch.bfloat16)
+    b = to_dev(rnd(4, "x.b", (N,), 0.1))
+    r0 = to_np(ops.gemm_nt(a, w, b, epilogue=EPI_STORE, out_dtype=torch.float32, use_mfma=0))
+    r1 = to_np(ops.gemm_nt(a, w, b, epilogue=EPI_STORE, out_dtype=torch.float32, use_mfma=1))
+    assert rel(r1, r0) < 2e-6
+
+
+def test_gemm_argument_errors(ops):
+    a, w = torch.zeros((8, 64), device=dev()), torch.zeros((24, 64), device=dev())
+    with pytest.raises(ValueError):
+        ops.gemm_nt(a, w)                                   # N % 16 != 0
+    with pytest.raises(Exception):
+        ops.gemm_nt(a, torch.zeros((32, 64), device=dev()), use_mfma=1)   # fp32 cannot take the MFMA kernel
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cols", [64, 320, 480, 2560, 4096])
+def test_norms(ops, cols):
+    rows = 37
+    x, w, b = rnd(5, "n.x", (rows, cols), 2.0, 0.3), rnd(5, "n.w", (cols,), 0.1, 1.0), rnd(5, "n.b", (cols,), 0.1)
+    for od, tol in ((torch.float32, 2e-6), (torch.bfloat16, 3e-3)):
+        y = to_np(ops.layernorm(to_dev(x), to_dev(w), to_dev(b), 1e-5, od))
+        assert rel(y[:, :cols], O.layer_norm(x, w, b, 1e-5)) < tol and not y[:, cols:].any()
+        y = to_np(ops.rmsnorm(to_dev(x), to_dev(w), 1e-5, od))
+        assert rel(y[:, :cols], O.rms_norm(x, w, 1e-5)) < tol and not y[:, cols:].any()
+
+
+def _attn_ref(q, k, v, mask, scale, causal):
+    """q [B,nh,T,d], k/v [B,nkv,T,d] fp32 -> [B,T,nh*d] via the oracle's softmax."""
+    B, nh, T, d = q.shape
+    rep = nh // k.shape[1]
+    k, v = np.repeat(k, rep, axis=1), np.repeat(v, rep, axis=1)
+    allowed = (mask[:, None, None, :] != 0)
+    if causal:
+        allowed = allowed & np.tril(np.ones((T, T), dtype=bool))[None, None]
+    s = np.einsum("bhqd,bhkd->bhqk", q, k).astype(np.float32) * np.float32(scale) + np.where(allowed, 0.0, O.NEG).astype(np.float32)
+    p = O.softmax_rows(s)
+    o = np.einsum("bhqk,bhkd->bhqd", p, v).astype(np.float32)
+    return o.transpose(0, 2, 1, 3).reshape(B, T, nh * d)
+
+
+ATTN_CASES = [  # B, T, nh, nkv, d, causal, lens
+    (2, 70, 4, 4, 16, False, [70, 33]),
+    (3, 128, 4, 4, 24, False, [128, 77, 5]),
+    (2, 200, 3, 3, 64, False, [200, 129]),
+    (2, 96, 8, 2, 64, True, [96, 40]),
+    (2, 130, 4, 1, 128, True, [130, 64]),
+    (1, 64, 2, 2, 32, False, [1]),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+@pytest.mark.parametrize("path", ["fp32", "mfma"])
+def test_qkv_post_and_attention(ops, case, path):
+    B, T, nh, nkv, d, causal, lens = case
+    dt = torch.float32 if path == "fp32" else torch.bfloat16
+    rq = (lambda x: x) if path == "fp32" else bf16r
+    width = (nh + 2 * nkv) * d
+    qkv = rq(rnd(6, "a.qkv", (B * T, width), 1.5))
+    mask = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    inv = O.default_inv_freq(10000.0, d)
+    cos, sin = O.rope_cos_sin(inv, np.arange(T))
+    x = qkv.reshape(B, T, nh + 2 * nkv, d).transpose(0, 2, 1, 3)
+    q_scale = d ** -0.5 if not causal else 1.0
+    scale = 1.0 if not causal else d ** -0.5
+    q = x[:, :nh] * np.float32(q_scale)
+    k, v = x[:, nh:nh + nkv], x[:, nh + nkv:]
+    q = rq(q * cos + O.rotate_half(q) * sin)
+    k = rq(k * cos + O.rotate_half(k) * sin)
+    key_mask, kv_info, _ = ops.mask_prepare(to_dev(mask))
+    assert to_np(kv_info)[:B].tolist() == lens and to_np(kv_info)[B:].tolist() == [1] * B
+    qd, kd, vtd = ops.qkv_post(to_dev(qkv, dt), to_dev(inv), B, T, nh, nkv, d, q_scale)
+    dp, tp = qd.shape[3], vtd.shape[3]
+    tol = 1e-6 if path == "fp32" else 4e-3
+    assert rel(to_np(qd)[..., :d], q) < tol and rel(to_np(kd)[..., :d], k) < tol
+    assert np.array_equal(to_np(vtd)[:, :, :d, :T], v.transpose(0, 1, 3, 2))
+    assert not to_np(qd)[..., d:].any() and not to_np(vtd)[:, :, d:, :].any() and not to_np(vtd)[..., T:].any()
+    out = ops.attention(qd, kd, vtd, key_mask, kv_info, d, scale, causal, use_mfma=(0 if path == "fp32" else 1))
+    got = to_np(out).reshape(B, T, -1)
+    ref = _attn_ref(to_np(qd)[..., :d], to_np(kd)[..., :d], v, mask, scale, causal)
+    for b, n in enumerate(lens):            # every query row, padded ones included (they see the valid keys)
+        assert rel(got[b, :, :nh * d], ref[b]) < (3e-6 if path == "fp32" else 8e-3), (b, n)
+    assert not got[..., nh * d:].any()
+
+
+def test_attention_non_prefix_mask(ops):
+    """A mask with a hole (not the right-padded contract) takes the byte-mask branch."""
+    B, T, nh, d = 1, 100, 2, 64
+    mask = np.ones((B, T), dtype=np.int64)
+    mask[0, 10:20] = 0
+    mask[0, 90:] = 0
+    qkv = bf16r(rnd(7, "h.qkv", (B * T, 3 * nh * d), 1.0))
+    inv = O.default_inv_freq(10000.0, d)
+    key_mask, kv_info, _ = ops.mask_prepare(to_dev(mask))
+    assert to_np(kv_info).tolist() == [90, 0]
+    qd, kd, vtd = ops.qkv_post(to_dev(qkv, torch.bfloat16), to_dev(inv), B, T, nh, nh, d, 1.0)
+    v = qkv.reshape(B, T, 3 * nh, d).transpose(0, 2, 1, 3)[:, 2 * nh:]
+    ref = _attn_ref(to_np(qd), to_np(kd), v, mask, 0.125, False)
+    for use in (0, 1):
+        got = to_np(ops.attention(qd, kd, vtd, key_mask, kv_info, d, 0.125, False, use_mfma=use)).reshape(B, T, -1)
+        assert rel(got[..., :nh * d], ref) < 8e-3
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["last", "mean", "std", "mix"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_readout_forward_backward(ops, mode, dt):
+    B, T, D = 5, 37, 72
+    emb = rnd(8, "r.e", (B, T, D), 2.0, 0.3)
+    if dt == torch.bfloat16:
+        emb = bf16r(emb)
+    lens = [37, 20, 9, 2, 1]
+    mask = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    e = to_dev(emb, dt)
+    got = to_np(ops.readout(e, to_dev(mask), mode))
+    ref = O.readout_embeddings(emb, mask, mode)
+    ok = np.isfinite(ref)
+    assert rel(got[ok], ref[ok]) < 3e-6
+    assert rel(to_np(ops.readout(e, None, mode)), O.readout_embeddings(emb, np.ones_like(mask), mode)) < 3e-6
+    d_out = rnd(8, "r.g", ref.shape, 1.0)
+    pooled = ops.readout(e, to_dev(mask), "mix") if mode in ("std", "mix") else None
+    g = to_np(ops.readout_backward(e, to_dev(mask), mode, pooled, to_dev(d_out)))
+    gref = O.readout_backward(emb, mask, mode, d_out)
+    rows = [b for b, n in enumerate(lens) if n > 1 or mode in ("last", "mean")]     # std of one token = 0 -> 0/0
+    assert rel(g[rows], gref[rows]) < 1e-5
+
+
+def test_l2norm_and_infonce(ops):
+    x = rnd(9, "l.x", (12, 256), 1.0, 0.1)
+    y = to_np(ops.l2norm_rows(to_dev(x)))
+    assert rel(y, O.l2_normalize(x)) < 1e-6
+    dy = rnd(9, "l.g", (12, 256), 1.0)
+    assert rel(to_np(ops.l2norm_rows_backward(to_dev(x), to_dev(dy))), O.l2_normalize_backward(x, dy)) < 2e-6
+    p, t = O.l2_normalize(rnd(9, "i.p", (6, 128))), O.l2_normalize(rnd(9, "i.t", (10, 128)))
+    labels = np.array([3, 9, 0, 4, 4, 7])
+    loss, logits = ops.infonce_forward(to_dev(p), to_dev(t), to_dev(labels))
+    ref_loss, ref_dp, ref_logits = O.infonce_segmented(p, t, labels, return_grad=True)
+    assert abs(float(to_np(loss)[0]) - float(ref_loss)) < 2e-6 * max(1.0, abs(float(ref_loss)))
+    assert rel(to_np(logits), ref_logits) < 1e-6
+    dp = ops.infonce_backward(to_dev(t), to_dev(labels), logits)
+    assert rel(to_np(dp), ref_dp) < 2e-6
+    # accumulate + weight (the segment loop of the step)
+    acc = torch.zeros((1,), device=dev())
+    ops.infonce_forward(to_dev(p[:3]), to_dev(t), to_dev(labels[:3]), weight=0.5, loss_out=acc, accumulate=False)
+    ops.infonce_forward(to_dev(p[3:]), to_dev(t), to_dev(labels[3:]), weight=0.5, loss_out=acc, accumulate=True)
+    two = 0.5 * (O.infonce_segmented(p[:3], t, labels[:3]) + O.infonce_segmented(p[3:], t, labels[3:]))
+    assert abs(float(to_np(acc)[0]) - float(two)) < 3e-6
+
+
+@pytest.mark.parametrize("max_norm", [math.inf, 0.05])
+def test_clip_adamw(ops, max_norm):
+    names = ["w1", "b1", "w2", "b2"]
+    shapes = [(48, 32), (48,), (64, 48), (64,)]
+    P = {n: rnd(10, "o.p" + n, s, 0.5) for n, s in zip(names, shapes)}
+    G = {n: rnd(10, "o.g" + n, s, 0.02) for n, s in zip(names, shapes)}
+    m = {n: np.zeros(s, np.float32) for n, s in zip(names, shapes)}
+    v = {n: np.zeros(s, np.float32) for n, s in zip(names, shapes)}
+    dp = [to_dev(P[n]) for n in names]
+    dm = [torch.zeros_like(t) for t in dp]
+    dv = [torch.zeros_like(t) for t in dp]
+    sh1 = torch.zeros((48, 64), dtype=torch.bfloat16, device=dev())
+    sh2 = torch.zeros((64, 64), dtype=torch.bfloat16, device=dev())
+    for step in (1, 2, 3):
+        gs = {n: G[n] * np.float32(step) for n in names}
+        gn_ref = O.clip_and_adamw(P, gs, m, v, step, max_norm=max_norm)
+        gn = ops.clip_adamw_step(dp, [to_dev(gs[n]) for n in names], dm, dv, step, max_norm=max_norm,
+                                 shadows=[sh1, None, sh2, None])
+        assert abs(float(to_np(gn)[0]) - float(gn_ref)) < 1e-5 * float(gn_ref)
+        for t, n in zip(dp, names):
+            np.testing.assert_allclose(to_np(t), P[n], rtol=2e-6, atol=1e-7)
+    assert np.array_equal(to_np(sh1)[:, :32], bf16r(to_np(dp[0]))) and not to_np(sh1)[:, 32:].any()
+    assert np.array_equal(to_np(sh2)[:, :48], bf16r(to_np(dp[2])))

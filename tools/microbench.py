@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the GPU box (HIP-event timed, random data): GEMM shapes of the
+cfg-3 towers, attention, norms.  Usage: python tools/microbench.py [gemm] [attn] [norm]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
+from p2t_hip import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def rand(shape, dtype=torch.bfloat16, scale=1.0):
+    t = torch.empty(shape, dtype=dtype, device=dev)
+    ops.fill_hash_(t, 1, f"mb{shape}", scale)
+    return t
+
+
+def bench_gemm():
+    shapes = [  # name, M, N, K, epilogue
+        ("esm qkv", 16384, 7680, 2560, 0), ("esm o", 16384, 2560, 2560, 2), ("esm fc1", 16384, 10240, 2560, 1),
+        ("esm fc2", 16384, 2560, 10240, 2), ("llama qkv", 2048, 6144, 4096, 0), ("llama o", 2048, 4096, 4096, 2),
+        ("llama gu", 2048, 28672, 4096, 3), ("llama down", 2048, 4096, 14336, 2), ("adapter fc1", 16384, 2048, 2560, 1),
+        ("adapter fc2", 16384, 4096, 2048, 1), ("square 4k", 4096, 4096, 4096, 0), ("square 8k", 8192, 8192, 8192, 0),
+    ]
+    for name, M, N, K, epi in shapes:
+        a, w = rand((M, K)), rand((N, K), scale=0.05)
+        bias = None if epi == 3 else rand((N,), torch.float32, 0.1)
+        out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
+        ms = timeit(lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1))
+        print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
+
+
+def bench_attn():
+    for name, B, T, nh, nkv, d, causal in [("esm3b", 16, 1024, 40, 40, 64, False), ("llama8b", 16, 128, 32, 8, 128, True),
+                                            ("esm35m", 32, 512, 20, 20, 24, False)]:
+        qkv = rand((B * T, (nh + 2 * nkv) * d))
+        inv = torch.ones((d // 2,), dtype=torch.float32, device=dev)
+        mask = torch.ones((B, T), dtype=torch.int64, device=dev)
+        km, kv, _ = ops.mask_prepare(mask)
+        q, k, vt = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0)
+        ms_post = timeit(lambda: ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0))
+        ms = timeit(lambda: ops.attention(q, k, vt, km, kv, d, d ** -0.5, causal, use_mfma=1))
+        fl = 4.0 * B * nh * T * T * d * (0.5 if causal else 1.0)
+        print(f"attn {name:8s} B={B} T={T} nh={nh}/{nkv} d={d}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s | qkv_post {ms_post:7.3f} ms", flush=True)
+
+
+def bench_norm():
+    for rows, cols in ((16384, 2560), (2048, 4096)):
+        x = rand((rows, cols), torch.float32)
+        w, b = rand((cols,), torch.float32), rand((cols,), torch.float32)
+        ms = timeit(lambda: ops.layernorm(x, w, b, 1e-5, torch.bfloat16))
+        print(f"layernorm {rows}x{cols}: {ms * 1e3:7.1f} us  {rows * cols * 6 / ms / 1e6:7.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "attn", "norm"]
+    print(torch.cuda.get_device_name(0), flush=True)
+    if "gemm" in which:
+        bench_gemm()
+    if "attn" in which:
+        bench_attn()
+    if "norm" in which:
+        bench_norm()
