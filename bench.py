@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: contrastive-step samples/s (protein-text pairs) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one synthetic batch, inputs resident in HBM: frozen text
+tower (Llama layers 1..16) -> frozen ESM2 encoder -> adapter forward -> readout / normalise ->
+all-gather of text embeddings (N > 1) -> InfoNCE -> adapter backward -> all-reduce of adapter grads
+(N > 1) -> clip + AdamW.  Default workload = BASELINE.json configs[2]: esm2_t36_3B +
+Llama-3.1-8B-Instruct shapes, bf16, 16 x 1024 residues / 16 x 128 text tokens per GPU, random-init
+weights and random residues/tokens from the repo's counter-hash generator (no checkpoints or
+datasets exist offline).  Weak scaling: per-GPU batch fixed, value = N * B * K / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs per launch / its mean launch duration,
+                  measured live with HIP events on the launch stream, vs the 2.5 PFLOP/s dense bf16 peak
+  "cpu_baseline": the numpy oracle (a port of the reference algorithm, fp32) timed on the host cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 | cfg4 (SURVEY.md section 8 table)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--segments", type=int, default=1, help="contrastive_num_segments")
+    ap.add_argument("--eval-mode", action="store_true", help="no adapter dropout (default: train mode, p=0.3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1, help="pairs in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+class GpuWeights:
+    """dict-like view of the GPU model's parameters as fp32 numpy (fetched per access, never all at once)."""
+
+    def __init__(self, model):
+        self.p = dict(model.named_parameters())
+        self.fetch_s = 0.0            # time spent downloading weights (excluded from the CPU-work figure)
+
+    def __getitem__(self, k):
+        t0 = time.perf_counter()
+        t = self.p[k]
+        if k.endswith("embed_tokens.weight") or k.endswith("word_embeddings.weight"):
+            return _Rows(t, self)
+        out = t.detach().float().cpu().numpy()
+        self.fetch_s += time.perf_counter() - t0
+        return out
+
+
+class _Rows:
+    def __init__(self, t, owner):
+        self.t, self.owner = t, owner
+
+    def __getitem__(self, ids):
+        import torch
+        t0 = time.perf_counter()
+        idx = torch.as_tensor(ids).to(self.t.device)
+        out = self.t.detach()[idx].float().cpu().numpy()
+        self.owner.fetch_s += time.perf_counter() - t0
+        return out
+
+
+def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs):
+    """Oracle forward + loss on `n_pairs` pairs of the same workload, host cores only."""
+    import numpy as np
+    from oracle import p2t_oracle as O
+    from p2t_hip import synth
+    from threadpoolctl import threadpool_limits
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))          # the GPU box gives one GPU a 16-core share
+    pid, pmask = synth.protein_batch(1234, n_pairs, Tp)
+    tid, tmask = synth.text_batch(1234, n_pairs, Tt)
+    W = GpuWeights(model)
+    with threadpool_limits(limits=cores):
+        t0 = time.perf_counter()
+        out = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=min(16, llama.num_hidden_layers), num_segments=1)
+        dt = time.perf_counter() - t0
+    assert np.isfinite(out["loss"])
+    work = dt - W.fetch_s
+    return {"value": round(n_pairs / work, 5), "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_pairs} pair(s) of {cfg_name} (T_p={Tp}, T_t={Tt}): fp32 numpy/OpenBLAS oracle, forward + InfoNCE, "
+                      f"{cores} BLAS threads, {work:.1f} s of CPU work (+{W.fetch_s:.1f} s downloading the GPU model's weights, excluded)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import p2t_hip as P
+    from p2t_hip import _lib, specs, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    esm_name, llama_name, dtype_name, B, Tp, Tt = specs.CONFIGS[args.config]
+    B = args.batch or B
+    esm, llama = specs.esm_spec(esm_name), specs.llama_spec(llama_name)
+    ad = specs.adapter_spec(esm, llama)
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    model = P.Esm2LlamaInstructForCausalLM.from_specs(esm, llama, ad, dtype=dtype, device=dev, seed=0)
+    model.esm_encoder.requires_grad_(False)
+    model.llama_decoder.requires_grad_(False)
+    trainer = P.ContrastiveTrainer(model, num_segments=args.segments, train_mode=not args.eval_mode, global_negatives=True)
+
+    pid, pmask = synth.protein_batch(1234 + rank, B, Tp)
+    tid, tmask = synth.text_batch(1234 + rank, B, Tt)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in dict(protein_input_ids=pid, protein_attention_mask=pmask,
+                                                              description_input_ids=tid, description_attention_mask=tmask).items()}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    barrier()
+    _lib.call("p2t_prof_enable", 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-kernel event times (synchronises the recorded events; outside the timed region)
+    ms = (ctypes.c_double * 2)()
+    cnt = (ctypes.c_int64 * 2)()
+    fl = (ctypes.c_double * 2)()
+    _lib.call("p2t_prof_collect", ms, cnt, fl, 2)
+    _lib.call("p2t_prof_enable", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.cpu()[0])
+
+    if rank == 0:
+        f = specs.flops_per_sample(esm, llama, ad, Tp, Tt, 16, backward=True)
+        value = world * B * args.steps / elapsed
+        step_tflops = f["total"] * B * args.steps / elapsed / 1e12          # per GPU
+        # dominant kernel: gemm_nt_mfma_kernel.  algorithmic GEMM FLOPs per sample = linear layers of both towers
+        # + adapter fwd/bwd (everything except the attention score/value products)
+        He, Le = esm.hidden_size, esm.num_hidden_layers
+        attn_flops = Le * 4 * Tp * Tp * He + min(16, llama.num_hidden_layers) * 2 * (Tt + 1) * Tt * llama.hidden_size
+        gemm_flops_step = (f["total"] - attn_flops) * B
+        launches_step = cnt[0] / args.steps
+        avg_ms = ms[0] / max(cnt[0], 1)
+        achieved = (gemm_flops_step / max(launches_step, 1)) / (avg_ms * 1e-3) / 1e12 if cnt[0] else 0.0
+        out = {
+            "metric": "contrastive-step samples/sec (protein-text pairs)", "value": round(value, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": f"{args.config}: {esm_name} + {llama_name} (text layers 1-16), per-GPU batch {B} x {Tp} residues / "
+                                   f"{B} x {Tt} text tokens, readout mix, InfoNCE tau=0.05, adapter fwd+bwd + clip + AdamW, "
+                                   f"{'train mode (dropout 0.3)' if not args.eval_mode else 'eval mode'}, segments {args.segments}",
+                       "global_batch": world * B, "parallelism": f"dp{world} (text-embedding all-gather + adapter-grad all-reduce over RCCL)",
+                       "algorithmic_tflop_per_sample": round(f["total"] / 1e12, 4),
+                       "step_tflops_per_gpu": round(step_tflops, 1), "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+                       "loss": round(loss_val, 5)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_mfma_kernel (bf16 16x16x32 MFMA GEMM, all epilogues)",
+                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": round(launches_step, 1), "avg_launch_ms": round(avg_ms, 4),
+                         "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attention_ms_per_step": round(ms[1] / args.steps, 3),
+                         "attention_tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, esm, llama, args.config, Tp, Tt, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,14 @@ const char* p2t_last_error(void);
  * 3 llama_config, 4 llama_layer, 5 llama_weights, 6 adapter_config, 7 adapter_weights, 8 adapter_saved. */
 size_t p2t_struct_size(int which);
 
+/* ---------------------------------------------------------------- measurement hooks (bench.py) */
+/* When enabled, every MFMA GEMM (class 0) and MFMA attention (class 1) launch is bracketed by HIP events on its
+ * own launch stream.  p2t_prof_collect synchronises those events (the only host sync in the library) and returns,
+ * per class, the summed kernel time in ms, the launch count and the algorithmic FLOPs (GEMM: 2 M N K; attention:
+ * 4 B nh T^2 d, halved when causal); it then resets the record list. */
+int p2t_prof_enable(int on);
+int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes);
+
 /* ---------------------------------------------------------------- synthetic data (bench / tests) */
 /* dst[i] = (int(hash24(i)) - 2^23) * scale23 + offset ; see p2t_hip/synth.py (bit-identical). */
 int p2t_fill_hash(void* dst, int64_t n, uint64_t add, uint64_t xorv, float scale23, float offset,

@@ -128,6 +128,27 @@ def softmax_rows(s):
 NEG = F32(np.finfo(np.float32).min)
 
 
+def attention_heads(q, k, v, bias, scale, prec):
+    """softmax(scale * q k^T + bias) v per (batch, head) -- the eager attention of ESM:292-317 and
+    LLAMA:191-213 -- evaluated head by head so the [T, T] score block stays cache-sized.
+    q [B,nh,T,d]; k, v [B,nkv,T,d] (GQA: query head h reads kv head h // (nh/nkv), i.e. repeat_kv);
+    bias broadcastable to [B, 1, T, T].  Returns [B, T, nh*d]."""
+    B, nh, T, d = q.shape
+    rep = nh // k.shape[1]
+    out = np.empty((B, T, nh * d), dtype=F32)
+    bias = np.broadcast_to(bias, (B, 1, T, T))
+    for b in range(B):
+        bb = bias[b, 0]
+        for h in range(nh):
+            s = q[b, h] @ k[b, h // rep].T
+            if scale != 1.0:
+                s *= F32(scale)
+            s += bb
+            pr = prec.q(softmax_rows(s))
+            out[b, :, h * d:(h + 1) * d] = pr @ v[b, h // rep]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # ESM2 encoder  (REF models/modeling_esm2llama_instruct.py:175-185 -> HF EsmModel.forward ESM:685-755)
 # ---------------------------------------------------------------------------------------------
@@ -169,10 +190,7 @@ def esm2_layer(spec, W, i, x, key_bias, cos, sin, prec: Precision = FP32, prefix
     q = q * cos + rotate_half(q) * sin                                    # ESM:74-79 (fp32)
     k = k * cos + rotate_half(k) * sin
     q, k, v = q_(q), q_(k), q_(v)
-    s = np.einsum("bhqd,bhkd->bhqk", q, k, optimize=True).astype(F32) + key_bias   # ESM:310-317
-    pr = q_(softmax_rows(s))
-    o = np.einsum("bhqk,bhkd->bhqd", pr, v, optimize=True).astype(F32)
-    o = q_(o.transpose(0, 2, 1, 3).reshape(B * T, H))
+    o = q_(attention_heads(q, k, v, key_bias, 1.0, prec).reshape(B * T, H))     # ESM:310-317, scale 1.0
     x = x + lin("attention.output.dense", o).reshape(B, T, H)               # ESM:399-409
     h = q_(layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], spec.layer_norm_eps))
     f = q_(gelu_erf(lin("intermediate.dense", h.reshape(B * T, H))))         # ESM:442-450
@@ -266,13 +284,7 @@ def llama_layer(spec, W, i, x, bias, cos, sin, prec: Precision = FP32, prefix=""
     q = q * cos + rotate_half(q) * sin
     k = k * cos + rotate_half(k) * sin
     q, k, v = q_(q), q_(k), q_(v)
-    rep = nh // nkv
-    k = np.repeat(k, rep, axis=1)
-    v = np.repeat(v, rep, axis=1)
-    s = np.einsum("bhqd,bhkd->bhqk", q, k, optimize=True).astype(F32) * F32(d ** -0.5) + bias
-    pr = q_(softmax_rows(s))
-    o = np.einsum("bhqk,bhkd->bhqd", pr, v, optimize=True).astype(F32)
-    o = q_(o.transpose(0, 2, 1, 3).reshape(B * T, nh * d))
+    o = q_(attention_heads(q, k, v, bias, d ** -0.5, prec).reshape(B * T, nh * d))
     x = x + (o @ q_(W[p + "self_attn.o_proj.weight"]).T).reshape(B, T, H)
     h = q_(rms_norm(x, W[p + "post_attention_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H)
     g = h @ q_(W[p + "mlp.gate_proj.weight"]).T

@@ -1,9 +1,40 @@
 // GEMM and attention dispatch: argument checks, kernel choice (MFMA vs fp32-FMA), C entry points.
+#include <vector>
+
 #include "common.h"
 #include "epilogue.h"
 #include "kernels.h"
 
 namespace p2t {
+
+// ---- optional in-library timing of the MFMA kernels (bench.py's live roofline measurement) ----------
+// HIP events are recorded on the launch stream right before / after each launch, so the elapsed time is
+// that kernel's own duration on the GPU; nothing synchronises until p2t_prof_collect.
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfRec> pool;
+    size_t used = 0;
+} g_prof;
+constexpr size_t kProfMax = 1 << 15;
+
+int prof_begin(hipStream_t s, int cls, double flops) {
+    if (!g_prof.on || g_prof.used >= kProfMax) return -1;
+    if (g_prof.used == g_prof.pool.size()) {
+        ProfRec r{};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+        g_prof.pool.push_back(r);
+    }
+    ProfRec& r = g_prof.pool[g_prof.used];
+    r.cls = cls; r.flops = flops;
+    if (hipEventRecord(r.a, s) != hipSuccess) return -1;
+    return (int)g_prof.used++;
+}
+void prof_end(hipStream_t s, int idx) {
+    if (idx >= 0) (void)hipEventRecord(g_prof.pool[idx].b, s);
+}
+}  // namespace
 
 int gemm_nt(const GemmArgs& a, hipStream_t s) {
     P2T_REQUIRE(a.A && a.W && a.out, "gemm_nt: null operand");
@@ -40,8 +71,12 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
                   (long long)a.K, (long long)a.lda, (long long)a.ldw);
         return P2T_ERR_UNSUPPORTED;
     }
-    if (can_mfma && a.use_mfma != 0)
-        return launch_gemm_mfma(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, out_dtype, a.epilogue, ep, a.tile, s);
+    if (can_mfma && a.use_mfma != 0) {
+        const int pi = prof_begin(s, 0, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+        const int rc = launch_gemm_mfma(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, out_dtype, a.epilogue, ep, a.tile, s);
+        prof_end(s, pi);
+        return rc;
+    }
     return launch_gemm_simple(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, a.dtype, out_dtype, a.epilogue, ep, s);
 }
 
@@ -50,8 +85,12 @@ int attention(const void* q, const void* k, const void* vt, const uint8_t* key_m
               int use_mfma, hipStream_t s) {
     P2T_REQUIRE(q && k && vt && key_mask && kv_info && out && B > 0 && T > 0 && nh > 0 && nkv > 0, "attention: bad arguments");
     P2T_REQUIRE(ld_out >= (int64_t)nh * d, "attention: ld_out too small");
-    if (dtype == P2T_BF16 && use_mfma != 0)
-        return launch_attn_mfma(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, s);
+    if (dtype == P2T_BF16 && use_mfma != 0) {
+        const int pi = prof_begin(s, 1, 4.0 * B * nh * (double)T * T * d * (causal ? 0.5 : 1.0));
+        const int rc = launch_attn_mfma(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, s);
+        prof_end(s, pi);
+        return rc;
+    }
     P2T_REQUIRE(use_mfma != 1, "attention: MFMA kernel needs bf16");
     return launch_attn_simple(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, dtype, s);
 }
@@ -59,6 +98,26 @@ int attention(const void* q, const void* k, const void* vt, const uint8_t* key_m
 }  // namespace p2t
 
 using namespace p2t;
+
+extern "C" int p2t_prof_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    return P2T_OK;
+}
+
+extern "C" int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes) {
+    P2T_REQUIRE(ms && launches && flops && n_classes >= 2, "p2t_prof_collect: bad arguments");
+    for (int c = 0; c < n_classes; ++c) { ms[c] = 0.0; launches[c] = 0; flops[c] = 0.0; }
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        ProfRec& r = g_prof.pool[i];
+        P2T_CHECK_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        P2T_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.cls < n_classes) { ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops; }
+    }
+    g_prof.used = 0;
+    return P2T_OK;
+}
 
 extern "C" int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                            void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,

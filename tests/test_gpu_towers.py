@@ -168,7 +168,9 @@ def test_bf16_mfma_step_matches_fp32_path_at_size():
                             num_key_value_heads=2, vocab_size=1024)
     ad = specs.AdapterSpec(esm.hidden_size, 256, llama.hidden_size, 0.0)
     B, Tp, Tt = 8, 300, 70
-    pid, pmask = synth.protein_batch(5, B, Tp, [300, 299, 180, 64, 65, 33, 7, 2])
+    # lengths >= 17: with 2-3 valid tokens a bf16 feature column can tie exactly -> std = 0 -> the 0/0 gradient of the
+    # reference's eps-free std readout (train_contrast.py:235); that is data-dependent reference behaviour, not under test here
+    pid, pmask = synth.protein_batch(5, B, Tp, [300, 299, 180, 64, 65, 33, 24, 17])
     tid, tmask = synth.text_batch(5, B, Tt, 1000, [70, 64, 50, 33, 20, 9, 3, 1], 1023, 1022)
     b = _batch(pid, pmask, tid, tmask)
     res = {}
