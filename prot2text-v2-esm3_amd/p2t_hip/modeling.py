@@ -129,6 +129,19 @@ class EsmEncoder(nn.Module):
         _init_tree(self)
         self._engine = None
         self._ws = _Workspace()
+        self._register_load_state_dict_pre_hook(self._remap_legacy_inv_freq)
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_engine())
+
+    @staticmethod
+    def _remap_legacy_inv_freq(state_dict, prefix, *args):
+        """Old ESM2 checkpoints store inv_freq per attention layer; keep the checkpoint's values (they may
+        have been saved in fp16) under the model-level key, as HF does (modeling_esm.py:654-674)."""
+        new_key = f"{prefix}rotary_embeddings.inv_freq"
+        old = sorted(k for k in list(state_dict) if k.startswith(prefix) and k.endswith(".attention.self.rotary_embeddings.inv_freq"))
+        if new_key not in state_dict and old:
+            state_dict[new_key] = state_dict[old[0]]
+        for k in old:
+            del state_dict[k]
 
     @property
     def dtype(self):
@@ -360,6 +373,7 @@ class LlamaTextModel(nn.Module):
         super().__init__()
         self.spec = spec
         self._engine, self._ws = None, _Workspace()
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_engine())
 
     @property
     def dtype(self):

@@ -63,15 +63,46 @@ def scale_f32(scale: float) -> np.float32:
     return np.float32(float(scale) / 8388608.0)
 
 
+_CHUNK = 1 << 18          # 256 Ki elements: the uint64 temporaries stay cache-resident
+
+
+def _fill_chunk(out, lo, hi, start, add, xor, s23, offset):
+    """out[lo:hi] = generator values for stream indices start+lo .. start+hi (in-place uint64 math)."""
+    with np.errstate(over="ignore"):
+        x = np.arange(start + lo, start + hi, dtype=np.uint64)
+        x += np.uint64(add)
+        x ^= np.uint64(xor)
+        t = x >> np.uint64(30); x ^= t; x *= _M1
+        np.right_shift(x, np.uint64(27), out=t); x ^= t; x *= _M2
+        np.right_shift(x, np.uint64(31), out=t); x ^= t
+        x >>= np.uint64(40)
+    v = x.astype(np.int32)
+    v -= np.int32(8388608)
+    f = v.astype(np.float32)
+    f *= s23
+    if offset != 0.0:
+        f += np.float32(offset)
+    out[lo:hi] = f
+
+
 def uniform_f32(seed: int, name: str, shape, scale: float, offset: float = 0.0,
                 start: int = 0) -> np.ndarray:
-    """fp32 tensor, uniform in [offset-scale, offset+scale); bit-identical to the HIP generator."""
+    """fp32 tensor, uniform in [offset-scale, offset+scale); bit-identical to the HIP generator.
+    Chunked and multi-threaded (numpy releases the GIL) so GB-sized towers materialise in seconds."""
     n = int(np.prod(shape)) if len(tuple(shape)) else 1
-    u = hash_u24(seed, name, start, n)
-    v = (u - 8388608).astype(np.float32) * scale_f32(scale)
-    if offset != 0.0:
-        v = v + np.float32(offset)
-    return v.reshape(shape)
+    add, xor = stream_key(seed, name)
+    s23 = scale_f32(scale)
+    out = np.empty((n,), dtype=np.float32)
+    spans = [(lo, min(lo + _CHUNK, n)) for lo in range(0, n, _CHUNK)]
+    if len(spans) <= 2:
+        for lo, hi in spans:
+            _fill_chunk(out, lo, hi, start, add, xor, s23, offset)
+    else:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda sp: _fill_chunk(out, sp[0], sp[1], start, add, xor, s23, offset), spans))
+    return out.reshape(shape)
 
 
 def uniform_rows_f32(seed: int, name: str, rows: np.ndarray, ncols: int, scale: float,

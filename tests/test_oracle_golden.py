@@ -72,3 +72,22 @@ def test_clip_adamw_step(golden, case):
     assert abs(gn - g["opt_gradnorm"]) < 1e-4 * max(1.0, float(g["opt_gradnorm"]))
     for n in names:
         np.testing.assert_allclose(params[n], g["opt_after_" + n[len("adapter."):]], rtol=1e-5, atol=2e-7)
+
+
+def test_cfg1_shapes_against_reference(golden):
+    """BASELINE.json configs[0]: esm2_t6_8M + Llama-3.2-1B shapes, B=4, T=128/64 (the reference's own
+    CPU-runnable case).  Weights (1.2 B parameters) are regenerated layer by layer from the hash generator."""
+    g = golden("cfg1")
+    meta = g["meta"]
+    esm, llama, ad, pid, pmask, tid, tmask = case_setup(meta)
+    W = model_weights(esm, llama, ad, meta["seed_w"], cache=False)
+    out = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=16, num_segments=2, with_grads=True)
+    assert rel_err(out["protein"], g["prot_norm_mix"]) < 5e-5
+    assert rel_err(out["text"], g["text_norm_mix_L16"]) < 5e-5
+    assert abs(out["loss"] - g["loss_seg2_mix_L16"]) < 5e-5
+    for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+        got = out["grads"]["adapter." + n]
+        if got.ndim == 2:
+            assert abs(np.linalg.norm(got.astype(np.float64)) - g[f"gradnorm_seg2_{n}"]) < 1e-3 * g[f"gradnorm_seg2_{n}"]
+            got = got[::7, ::5]
+        assert rel_err(got, g[f"grad_seg2_{n}"]) < 1e-3, n
