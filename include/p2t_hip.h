@@ -39,9 +39,10 @@ enum {                                                     /* GEMM epilogues (p2
     P2T_EPI_STORE = 0,      /* C = acc + bias                                   */
     P2T_EPI_GELU = 1,       /* C = gelu_erf(acc + bias); optional Z = acc + bias */
     P2T_EPI_RESID = 2,      /* R(f32, in place) += acc + bias                   */
-    P2T_EPI_SWIGLU = 3,     /* C[m, f] = silu(gate) * up, gate/up interleaved by 16 rows of W */
+    P2T_EPI_SWIGLU = 3,     /* C[m, f] = silu(gate) * up, gate/up interleaved by 32 rows of W */
     P2T_EPI_STORE_F32 = 4,  /* C(f32) = acc (+ C if accumulate)                  */
-    P2T_EPI_GELU_BWD = 5    /* C = acc * gelu_erf'(Z), Z read from z (adapter backward) */
+    P2T_EPI_GELU_BWD = 5,   /* C = acc * gelu_erf'(Z), Z read from z (adapter backward) */
+    P2T_EPI_QKV_ROPE = 6    /* internal to the towers: bias + q-scale + rotary + head split, head_dim 64 */
 };
 
 typedef void* p2t_stream;
@@ -77,7 +78,7 @@ int p2t_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, v
  * (v_mfma_f32_16x16x32_bf16, 256x256x64 LDS tiles); otherwise the fp32-FMA kernel.  bias: f32 [N] or NULL.
  * out: `out_dtype` [M, ldc]; columns N..min(ldc, N rounded up to 64)-1 are written as zeros (they are the zero
  * K-padding of the next GEMM).  z (GELU only, may be NULL): pre-activation, out_dtype, same stride.  EPI_RESID: out is f32 and accumulated in place.  EPI_SWIGLU: N is the
- * interleaved gate/up row count, out has N/2 columns.  use_mfma: -1 auto, 0 force FMA kernel, 1 require MFMA. */
+ * interleaved gate/up row count (a multiple of 64), out has N/2 columns.  use_mfma: -1 auto, 0 force FMA kernel, 1 require MFMA. */
 int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                 void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
                 int use_mfma, p2t_stream stream);
@@ -94,19 +95,19 @@ int p2t_rmsnorm(const float* x, int64_t ld_x, const float* w, float eps, void* y
  * numerator, denominator; needs ids). */
 int p2t_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
                      uint8_t* key_mask, int32_t* kv_info, float* emb_scale, p2t_stream stream);
-/* Head split + query scale + rotary + V transpose.  qkv `dtype` [B*T, ldq] rows = [q heads | k heads | v heads];
- * inv_freq f32 [d/2]; cos_sin_scratch f32 [T * d].  Outputs as p2t_attention expects them. */
+/* Head split + query scale + rotary.  qkv `dtype` [B*T, ldq] rows = [q heads | k heads | v heads];
+ * inv_freq f32 [d/2]; cos_sin_scratch f32 [T * d].  Outputs q [B, nh, T, dp], k and v [B, nkv, T, dp], head dim
+ * zero-padded to dp in {32, 64, 128}.  (For head_dim 64 the towers fuse this pass into the QKV GEMM epilogue.) */
 int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos_sin_scratch, void* q, void* k,
-                 void* vt, int B, int T, int nh, int nkv, int d, int dp, int tp, float q_scale, int dtype,
-                 p2t_stream stream);
+                 void* v, int B, int T, int nh, int nkv, int d, int dp, float q_scale, int dtype, p2t_stream stream);
 
-/* Attention.  q [B, nh, T, dp], k [B, nkv, T, dp], vt [B, nkv, dp, tp] (V transposed, tp = T rounded up
- * to 64), all `dtype`; head dim padded with zeros to dp in {32, 64, 128}.  key_mask u8 [B, T] (1 = valid),
- * kv_info i32 [2B] from p2t_mask_prepare.  softmax(scale * q k^T + mask) v -> out [B*T, ld_out] `dtype`,
- * head h in columns h*d..h*d+d-1; columns nh*d..ld_out-1 zeroed.  causal: also require key <= query. */
-int p2t_attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info,
-                  void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale,
-                  int causal, int dtype, int use_mfma, p2t_stream stream);
+/* Attention.  q [B, nh, T, dp], k and v [B, nkv, T, dp], all `dtype`, row-major (the MFMA kernel transposes V with
+ * ds_read_b64_tr_b16).  key_mask u8 [B, T] (1 = valid), kv_info i32 [2B] from p2t_mask_prepare.
+ * softmax(scale * q k^T + mask) v -> out [B*T, ld_out] `dtype`, head h in columns h*d..h*d+d-1; columns nh*d up to the
+ * next multiple of 64 (the o-proj K padding) zeroed.  causal: also require key <= query. */
+int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
+                  void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
+                  int dtype, int use_mfma, p2t_stream stream);
 
 /* ---------------------------------------------------------------- ESM2 encoder */
 typedef struct {
@@ -153,8 +154,8 @@ typedef struct {
     int32_t dtype;
 } p2t_llama_config;
 
-/* qkv_w rows: q (heads*d), k (kv*d), v (kv*d).  gu_w: gate/up interleaved in blocks of 16 rows
- * (rows 32j..32j+15 = gate 16j.., rows 32j+16..32j+31 = up 16j..).  No biases. */
+/* qkv_w rows: q (heads*d), k (kv*d), v (kv*d).  gu_w: gate/up interleaved in blocks of 32 rows
+ * (rows 64j..64j+31 = gate features 32j.., rows 64j+32..64j+63 = up features 32j..).  No biases. */
 typedef struct {
     const void* qkv_w; const void* o_w; const void* gu_w; const void* down_w;
     const float* ln1_w;                              /* input_layernorm */

@@ -108,6 +108,7 @@ extern "C" size_t p2t_adapter_backward_workspace_bytes(const p2t_adapter_config*
     n += (size_t)I * ld2 * e + 256;        // W2^T
     n += (size_t)M * ld1 * e + 256;        // dz1
     n += (size_t)X * Mp * e + 256;         // x^T
+    n += colsum_scratch_bytes(O > I ? O : I) + 256;
     return n + 1024;
 }
 
@@ -132,11 +133,12 @@ extern "C" int p2t_adapter_backward(const p2t_adapter_config* cfg, const p2t_ada
     void* w2T = ar.take((size_t)I * ld2 * e);
     void* dz1 = ar.take((size_t)M * ld1 * e);
     void* xT = ar.take((size_t)X * Mp * e);
+    float* cs_scratch = (float*)ar.take(colsum_scratch_bytes(O > I ? O : I));
     P2T_REQUIRE(!ar.overflow, "p2t_adapter_backward: workspace overflow");
 
     P2T_TRY(launch_adapter_dz2(saved->g2, saved->z2, saved->inv_norm, dy, dz2, ld2, M, (int)O, dt, cfg->dropout_p,
                                cfg->dropout_seed ^ kSeed2, s));
-    P2T_TRY(launch_colsum(dz2, dt, M, O, ld2, d_fc2_b, accumulate, s));
+    P2T_TRY(launch_colsum(dz2, dt, M, O, ld2, d_fc2_b, accumulate, cs_scratch, s));
     P2T_TRY(p2t_transpose(dz2, M, O, ld2, dz2T, Mp, dt, stream));
     P2T_TRY(p2t_transpose(saved->h1, M, I, ld1, h1T, Mp, dt, stream));
     {   // dW2 [O, I] = dz2^T [O, M] . (h1^T [I, M])^T
@@ -149,7 +151,7 @@ extern "C" int p2t_adapter_backward(const p2t_adapter_config* cfg, const p2t_ada
                    cfg->dropout_p, cfg->dropout_seed, 0};
         P2T_TRY(gemm_nt(g, s));
     }
-    P2T_TRY(launch_colsum(dz1, dt, M, I, ld1, d_fc1_b, accumulate, s));
+    P2T_TRY(launch_colsum(dz1, dt, M, I, ld1, d_fc1_b, accumulate, cs_scratch, s));
     void* dz1T = h1T;   // h1^T is dead after dW2
     P2T_TRY(p2t_transpose(dz1, M, I, ld1, dz1T, Mp, dt, stream));
     P2T_TRY(p2t_transpose(x, M, X, ld_x, xT, Mp, dt, stream));

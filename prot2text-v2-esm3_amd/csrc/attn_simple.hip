@@ -1,6 +1,6 @@
 // Exact-fp32 attention (parity mode and fallback): one wavefront per query row, online softmax
 // over 64-key chunks.  Phase 1 puts keys on lanes (scores, running max / sum), phase 2 puts the
-// head channels on lanes and accumulates P.V from the transposed V ([dp][tp], contiguous in keys).
+// head channels on lanes and accumulates P.V from V ([keys][dp] row-major: coalesced across lanes).
 //   ESM:   bidirectional + key padding, scale 1.0 (q pre-scaled), modeling_esm.py:292-317
 //   Llama: causal + key padding, GQA, fp32 softmax, modeling_llama.py:191-213
 // Rows with no visible key produce zeros (the reference would average all keys; not reachable with
@@ -12,9 +12,9 @@ namespace p2t {
 
 template <typename T>
 __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                          const T* __restrict__ vt, const uint8_t* __restrict__ key_mask,
+                                                          const T* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                           const int32_t* __restrict__ kv_end, T* __restrict__ out,
-                                                          int64_t ld_out, int seq, int nh, int nkv, int d, int dp, int tp,
+                                                          int64_t ld_out, int seq, int nh, int nkv, int d, int dp,
                                                           float scale, int causal, int out_cols) {
     __shared__ float s_q[4][128];
     __shared__ float s_p[4][64];
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ 
     const int hk = h / (nh / nkv);
     const T* qrow = q + ((int64_t)(b * nh + h) * seq + i) * dp;
     const T* kbase = k + ((int64_t)(b * nkv + hk) * seq) * dp;
-    const T* vbase = vt + ((int64_t)(b * nkv + hk) * dp) * tp;
+    const T* vbase = v + ((int64_t)(b * nkv + hk) * seq) * dp;
     for (int c = lane; c < dp; c += 64) s_q[w][c] = to_f32(qrow[c]);
     int end = kv_end[b];
     if (causal) end = min(end, i + 1);
@@ -58,12 +58,12 @@ __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ 
         acc1 *= alpha;
         const int nj = min(64, end - j0);
         if (lane < d) {
-            const T* vr = vbase + (int64_t)lane * tp + j0;
-            for (int jj = 0; jj < nj; ++jj) acc0 = fmaf(s_p[w][jj], to_f32(vr[jj]), acc0);
+            const T* vr = vbase + (int64_t)j0 * dp + lane;
+            for (int jj = 0; jj < nj; ++jj) acc0 = fmaf(s_p[w][jj], to_f32(vr[(int64_t)jj * dp]), acc0);
         }
         if (lane + 64 < d) {
-            const T* vr = vbase + (int64_t)(lane + 64) * tp + j0;
-            for (int jj = 0; jj < nj; ++jj) acc1 = fmaf(s_p[w][jj], to_f32(vr[jj]), acc1);
+            const T* vr = vbase + (int64_t)j0 * dp + lane + 64;
+            for (int jj = 0; jj < nj; ++jj) acc1 = fmaf(s_p[w][jj], to_f32(vr[(int64_t)jj * dp]), acc1);
         }
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -74,18 +74,18 @@ __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ 
         for (int c = nh * d + lane; c < out_cols; c += 64) out[((int64_t)b * seq + i) * ld_out + c] = from_f32<T>(0.f);
 }
 
-int launch_attn_simple(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_end,
-                       void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale,
+int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_end,
+                       void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale,
                        int causal, int dtype, hipStream_t s) {
     P2T_REQUIRE(d % 4 == 0 && d <= 128 && dp <= 128 && nh % nkv == 0, "attention: head_dim %d / heads %d/%d unsupported", d, nh, nkv);
     const dim3 grid((unsigned)ceil_div(T, 4), (unsigned)nh, (unsigned)B);
     const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
     if (dtype == P2T_BF16)
-        attn_simple_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, key_mask, kv_end,
-                                                        (bf16_t*)out, ld_out, T, nh, nkv, d, dp, tp, scale, causal, out_cols);
+        attn_simple_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_end,
+                                                        (bf16_t*)out, ld_out, T, nh, nkv, d, dp, scale, causal, out_cols);
     else
-        attn_simple_kernel<float><<<grid, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)vt, key_mask, kv_end,
-                                                       (float*)out, ld_out, T, nh, nkv, d, dp, tp, scale, causal, out_cols);
+        attn_simple_kernel<float><<<grid, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, key_mask, kv_end,
+                                                       (float*)out, ld_out, T, nh, nkv, d, dp, scale, causal, out_cols);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -124,12 +124,11 @@ __global__ void __launch_bounds__(256) rope_table_kernel(const float* __restrict
 
 // grid (ceil(T/64), nh + 2*nkv, B).  qkv row m: [q heads | k heads | v heads], row stride ldq.
 // q: [B, nh, T, dp]  k: [B, nkv, T, dp] (scaled / rotated, zero padded to dp)
-// vt: [B, nkv, dp, tp] (transposed through LDS so both the read and the write are coalesced)
+// v: [B, nkv, T, dp] (row-major like k: the attention kernels transpose on the fly)
 template <typename T>
 __global__ void __launch_bounds__(256) qkv_post_kernel(const T* __restrict__ qkv, int64_t ldq, const float* __restrict__ cs,
-                                                       T* __restrict__ q, T* __restrict__ k, T* __restrict__ vt, int seq,
-                                                       int nh, int nkv, int d, int dp, int tp, float q_scale) {
-    __shared__ float tile[64][129];
+                                                       T* __restrict__ q, T* __restrict__ k, T* __restrict__ v, int seq,
+                                                       int nh, int nkv, int d, int dp, float q_scale) {
     const int b = blockIdx.z, hh = blockIdx.y, t0 = blockIdx.x * 64;
     const int half = d / 2;
     if (hh < nh + nkv) {
@@ -166,15 +165,10 @@ __global__ void __launch_bounds__(256) qkv_post_kernel(const T* __restrict__ qkv
     } else {
         const int head = hh - nh - nkv;
         const int col0 = (nh + nkv) * d + head * d;
-        for (int i = threadIdx.x; i < 64 * d; i += 256) {
-            const int tl = i / d, c = i % d, t = t0 + tl;
-            tile[tl][c] = t < seq ? to_f32(qkv[((int64_t)b * seq + t) * ldq + col0 + c]) : 0.f;
-        }
-        __syncthreads();
-        T* dst = vt + ((int64_t)(b * nkv + head) * dp) * tp;
+        T* dst = v + ((int64_t)(b * nkv + head) * seq) * dp;
         for (int i = threadIdx.x; i < 64 * dp; i += 256) {
-            const int c = i / 64, tl = i % 64, t = t0 + tl;
-            if (t < tp) dst[(int64_t)c * tp + t] = from_f32<T>(c < d ? tile[tl][c] : 0.f);
+            const int tl = i / dp, c = i % dp, t = t0 + tl;
+            if (t < seq) dst[(int64_t)t * dp + c] = c < d ? qkv[((int64_t)b * seq + t) * ldq + col0 + c] : from_f32<T>(0.f);
         }
     }
 }
@@ -221,14 +215,14 @@ int launch_rope_table(const float* inv_freq, int T, int half, float* cs, hipStre
     return P2T_OK;
 }
 
-int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* vt, int B, int T, int nh,
-                    int nkv, int d, int dp, int tp, float q_scale, int dtype, hipStream_t s) {
+int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* v, int B, int T, int nh,
+                    int nkv, int d, int dp, float q_scale, int dtype, hipStream_t s) {
     P2T_REQUIRE(d % 2 == 0 && d <= 128 && dp >= d && dp <= 128 && dp % 2 == 0, "qkv_post: head_dim %d (padded %d) unsupported", d, dp);
-    const dim3 grid((unsigned)ceil_div(tp, 64), (unsigned)(nh + 2 * nkv), (unsigned)B);
+    const dim3 grid((unsigned)ceil_div(T, 64), (unsigned)(nh + 2 * nkv), (unsigned)B);
     if (dtype == P2T_BF16)
-        qkv_post_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)qkv, ldq, cs, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, T, nh, nkv, d, dp, tp, q_scale);
+        qkv_post_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)qkv, ldq, cs, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, T, nh, nkv, d, dp, q_scale);
     else
-        qkv_post_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, ldq, cs, (float*)q, (float*)k, (float*)vt, T, nh, nkv, d, dp, tp, q_scale);
+        qkv_post_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, ldq, cs, (float*)q, (float*)k, (float*)v, T, nh, nkv, d, dp, q_scale);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -1,9 +1,12 @@
 // GEMM epilogues shared by the fp32-FMA kernel (gemm_simple.hip) and the bf16 MFMA kernel
-// (gemm_mfma.hip).  A kernel hands over, for one output row m, two groups of 4 consecutive
-// columns: v0 at n0..n0+3 and v1 at n0+16..n0+19 with (n0 % 32) < 16 -- the shape both the
-// 16x16 MFMA accumulator fragment (swapped operands: a lane owns 4 consecutive n of one m) and
-// the FMA micro-tile produce.  The +16 partner is what lets SwiGLU (gate/up interleaved in
-// 16-row blocks of the packed weight) finish in registers.
+// (gemm_mfma.hip).  A kernel hands over, for one output row m, two groups of W consecutive columns:
+// v0 at n .. n+W-1 and v1 at n+32 .. n+32+W-1 with (n % 64) < 32, plus the matching bias values.
+// The +32 partner is what lets the pairwise epilogues finish in registers:
+//   * SwiGLU      -- gate/up rows interleaved in 32-row blocks of the packed weight (rows 64g..64g+31 = gate
+//                    features 32g.., rows 64g+32..64g+63 = up features 32g..);
+//   * QKV + RoPE  -- head_dim 64: column j and its rotate-half partner j+32 of the same head.
+// W = 8 for the MFMA kernel (its W-row permutation gives a lane 8 consecutive columns -> 16-byte bf16 stores),
+// W = 4 for the FMA kernel.
 #pragma once
 #include "common.h"
 
@@ -12,15 +15,20 @@ namespace p2t {
 struct EpiParams {
     const float* bias;      // [N] or nullptr
     void* out;              // [M, ldc]
-    void* z;                // optional pre-activation (GELU), same layout as out
+    void* z;                // optional pre-activation (GELU: written; GELU_BWD: read), same layout as out
     int64_t ldc;
     int64_t M;
     int N;                  // logical columns of the GEMM (rows of W)
     int n_zero;             // output columns [N_out, n_zero) are written as zeros (K padding of the consumer)
     int accumulate;
-    float drop_p;           // GELU only: dropout on the activation output
+    float drop_p;           // GELU / GELU_BWD: dropout on the activation output
     float drop_scale;       // 1 / (1 - p)
     uint64_t drop_seed;
+    // QKV + RoPE epilogue (head_dim 64): outputs [B, heads, T, 64]
+    const float* cs;        // [T, 64]: cos (32) | sin (32)
+    void* q; void* k; void* v;
+    int seq, nh, nkv;
+    float q_scale;
 };
 
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t idx, float p) {
@@ -28,140 +36,201 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t idx, float p
     return (float)u >= p * 16777216.0f;
 }
 
+template <int W> __device__ __forceinline__ void storeW(float* p, const float (&v)[W]) {
+#pragma unroll
+    for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+}
+template <int W> __device__ __forceinline__ void storeW(bf16_t* p, const float (&v)[W]) {
+    if constexpr (W == 8) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                  pack_bf16x2(v[6], v[7]));
+    } else {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+}
+template <int W> __device__ __forceinline__ void loadW(const float* p, float (&v)[W]) {
+#pragma unroll
+    for (int c = 0; c < W; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + c);
+        v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+    }
+}
+template <int W> __device__ __forceinline__ void loadW(const bf16_t* p, float (&v)[W]) {
+    if constexpr (W == 8) {
+        load8(p, v);
+    } else {
+        load4(p, v);
+    }
+}
+template <int W> __device__ __forceinline__ void zeroW(float (&v)[W]) {
+#pragma unroll
+    for (int c = 0; c < W; ++c) v[c] = 0.f;
+}
+
+// Every functor: group(p, m, n, v, b) handles W consecutive columns starting at n; apply2 = both groups.
+#define P2T_EPI_APPLY2                                                                                          \
+    template <int W>                                                                                            \
+    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W],   \
+                                                  const float (&v1)[W], const float (&b0)[W], const float (&b1)[W]) { \
+        group<W>(p, m, n, v0, b0);                                                                              \
+        group<W>(p, m, n + 32, v1, b1);                                                                         \
+    }
+
 template <typename Tout>
 struct EpiStore {
-    static constexpr bool kPair = false;
-    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[4]) {
+    template <int W>
+    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
+        float r[W];
         if (n < p.N) {
-            float r[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = v[j] + (p.bias ? p.bias[n + j] : 0.f);
-            store4(o, r);
+            for (int j = 0; j < W; ++j) r[j] = v[j] + b[j];
+            storeW<W>(o, r);
         } else if (n < p.n_zero) {
-            const float zz[4] = {0.f, 0.f, 0.f, 0.f};
-            store4(o, zz);
+            zeroW<W>(r);
+            storeW<W>(o, r);
         }
     }
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n0, const float (&v0)[4],
-                                                  const float (&v1)[4]) {
-        group(p, m, n0, v0);
-        group(p, m, n0 + 16, v1);
-    }
+    P2T_EPI_APPLY2
 };
 
 template <typename Tout>
 struct EpiGelu {
-    static constexpr bool kPair = false;
-    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[4]) {
+    template <int W>
+    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
+        float zv[W], r[W];
         if (n < p.N) {
-            float zv[4], r[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                zv[j] = v[j] + (p.bias ? p.bias[n + j] : 0.f);
-                r[j] = gelu_erf(zv[j]);
+            for (int j = 0; j < W; ++j) {
+                zv[j] = v[j] + b[j];
+                r[j] = gelu_erf_for<Tout>(zv[j]);
                 if (p.drop_p > 0.f) r[j] = dropout_keep(p.drop_seed, m * (int64_t)p.N + n + j, p.drop_p) ? r[j] * p.drop_scale : 0.f;
             }
-            if (p.z) store4((Tout*)p.z + m * p.ldc + n, zv);
-            store4(o, r);
+            if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, zv);
+            storeW<W>(o, r);
         } else if (n < p.n_zero) {
-            const float zz[4] = {0.f, 0.f, 0.f, 0.f};
-            store4(o, zz);
-            if (p.z) store4((Tout*)p.z + m * p.ldc + n, zz);
+            zeroW<W>(r);
+            storeW<W>(o, r);
+            if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, r);
         }
     }
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n0, const float (&v0)[4],
-                                                  const float (&v1)[4]) {
-        group(p, m, n0, v0);
-        group(p, m, n0 + 16, v1);
-    }
+    P2T_EPI_APPLY2
 };
 
 // backward through dropout(gelu(z)): out = acc * gelu'(z) * dropout_mask; z is READ (layout of out)
 template <typename Tout>
 struct EpiGeluBwd {
-    static constexpr bool kPair = false;
-    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[4]) {
+    template <int W>
+    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
+        float zv[W], r[W];
         if (n < p.N) {
-            float zv[4], r[4];
-            load4((const Tout*)p.z + m * p.ldc + n, zv);
+            loadW<W>((const Tout*)p.z + m * p.ldc + n, zv);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < W; ++j) {
                 r[j] = v[j] * gelu_erf_grad(zv[j]);
                 if (p.drop_p > 0.f) r[j] = dropout_keep(p.drop_seed, m * (int64_t)p.N + n + j, p.drop_p) ? r[j] * p.drop_scale : 0.f;
             }
-            store4(o, r);
+            storeW<W>(o, r);
         } else if (n < p.n_zero) {
-            const float zz[4] = {0.f, 0.f, 0.f, 0.f};
-            store4(o, zz);
+            zeroW<W>(r);
+            storeW<W>(o, r);
         }
     }
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n0, const float (&v0)[4],
-                                                  const float (&v1)[4]) {
-        group(p, m, n0, v0);
-        group(p, m, n0 + 16, v1);
-    }
+    P2T_EPI_APPLY2
 };
 
 // residual stream (f32) += acc + bias, in place
 struct EpiResid {
-    static constexpr bool kPair = false;
-    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[4]) {
+    template <int W>
+    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         if (n >= p.N) return;
         float* o = (float*)p.out + m * p.ldc + n;
-        float r[4];
-        load4(o, r);
+        float r[W];
+        loadW<W>(o, r);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] += v[j] + (p.bias ? p.bias[n + j] : 0.f);
-        store4(o, r);
+        for (int j = 0; j < W; ++j) r[j] += v[j] + b[j];
+        storeW<W>(o, r);
     }
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n0, const float (&v0)[4],
-                                                  const float (&v1)[4]) {
-        group(p, m, n0, v0);
-        group(p, m, n0 + 16, v1);
-    }
+    P2T_EPI_APPLY2
 };
 
 // f32 store / accumulate (gradients)
 struct EpiF32 {
-    static constexpr bool kPair = false;
-    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[4]) {
+    template <int W>
+    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         if (n >= p.N) return;
         float* o = (float*)p.out + m * p.ldc + n;
-        float r[4] = {v[0], v[1], v[2], v[3]};
+        float r[W];
         if (p.accumulate) {
-            float c[4];
-            load4(o, c);
+            loadW<W>(o, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] += c[j];
+            for (int j = 0; j < W; ++j) r[j] += v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < W; ++j) r[j] = v[j];
         }
-        store4(o, r);
+        storeW<W>(o, r);
     }
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n0, const float (&v0)[4],
-                                                  const float (&v1)[4]) {
-        group(p, m, n0, v0);
-        group(p, m, n0 + 16, v1);
+    P2T_EPI_APPLY2
+};
+
+// out[m, f] = silu(gate_f) * up_f with f = (n / 64) * 32 + (n % 32): gate in the first group, up in the partner.
+template <typename Tout>
+struct EpiSwiglu {
+    template <int W>
+    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&g)[W], const float (&u)[W],
+                                                  const float (&b0)[W], const float (&b1)[W]) {
+        const int f = (n >> 6) * 32 + (n & 31);
+        Tout* o = (Tout*)p.out + m * p.ldc + f;
+        float r[W];
+        if (n < p.N) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) r[j] = silu(g[j]) * u[j];
+            storeW<W>(o, r);
+        } else if (f < p.n_zero) {
+            zeroW<W>(r);
+            storeW<W>(o, r);
+        }
     }
 };
 
-// out[m, f] = silu(gate_f) * up_f; packed W rows 32j..32j+15 = gate features 16j.., rows 32j+16.. = up.
+// QKV projection + bias + query scale + rotary (rotate-half pairs j, j+32 of a 64-wide head) + head split:
+// q [B, nh, T, 64], k [B, nkv, T, 64], v [B, nkv, T, 64].  Restates HF EsmSelfAttention.forward up to the
+// attention call (modeling_esm.py:362-378) and LlamaAttention.forward (modeling_llama.py:254-259) for d = 64.
 template <typename Tout>
-struct EpiSwiglu {
-    static constexpr bool kPair = true;
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n0, const float (&g)[4],
-                                                  const float (&u)[4]) {
-        const int f = (n0 >> 5) * 16 + (n0 & 15);
-        Tout* o = (Tout*)p.out + m * p.ldc + f;
-        if (n0 < p.N) {
-            float r[4];
+struct EpiQkvRope {
+    template <int W>
+    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
+                                                  const float (&b0)[W], const float (&b1)[W]) {
+        if (n >= p.N) return;
+        const int head = n >> 6, j = n & 31;
+        const int b = (int)(m / p.seq), t = (int)(m - (int64_t)b * p.seq);
+        float x1[W], x2[W];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = silu(g[j]) * u[j];
-            store4(o, r);
-        } else if (f < p.n_zero) {
-            const float zz[4] = {0.f, 0.f, 0.f, 0.f};
-            store4(o, zz);
+        for (int e = 0; e < W; ++e) { x1[e] = v0[e] + b0[e]; x2[e] = v1[e] + b1[e]; }
+        Tout* dst;
+        if (head < p.nh + p.nkv) {
+            const bool is_q = head < p.nh;
+            const float sc = is_q ? p.q_scale : 1.0f;
+            float c[W], s[W], o1[W], o2[W];
+            loadW<W>(p.cs + (int64_t)t * 64 + j, c);
+            loadW<W>(p.cs + (int64_t)t * 64 + 32 + j, s);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float a1 = x1[e] * sc, a2 = x2[e] * sc;
+                o1[e] = a1 * c[e] - a2 * s[e];
+                o2[e] = a2 * c[e] + a1 * s[e];
+            }
+            dst = is_q ? (Tout*)p.q + (((int64_t)b * p.nh + head) * p.seq + t) * 64
+                       : (Tout*)p.k + (((int64_t)b * p.nkv + (head - p.nh)) * p.seq + t) * 64;
+            storeW<W>(dst + j, o1);
+            storeW<W>(dst + 32 + j, o2);
+        } else {
+            dst = (Tout*)p.v + (((int64_t)b * p.nkv + (head - p.nh - p.nkv)) * p.seq + t) * 64;
+            storeW<W>(dst + j, x1);
+            storeW<W>(dst + 32 + j, x2);
         }
     }
 };

@@ -37,17 +37,20 @@ void prof_end(hipStream_t s, int idx) {
 }  // namespace
 
 int gemm_nt(const GemmArgs& a, hipStream_t s) {
-    P2T_REQUIRE(a.A && a.W && a.out, "gemm_nt: null operand");
+    P2T_REQUIRE(a.A && a.W && (a.out || a.epilogue == P2T_EPI_QKV_ROPE), "gemm_nt: null operand");
     P2T_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0 && a.N < (1 << 30) && a.K < (1 << 30), "gemm_nt: bad sizes M=%lld N=%lld K=%lld",
                 (long long)a.M, (long long)a.N, (long long)a.K);
     if (a.M == 0) return P2T_OK;
     const bool swiglu = a.epilogue == P2T_EPI_SWIGLU;
-    P2T_REQUIRE(a.N % (swiglu ? 32 : 16) == 0, "gemm_nt: N=%lld must be a multiple of %d", (long long)a.N, swiglu ? 32 : 16);
+    const bool rope = a.epilogue == P2T_EPI_QKV_ROPE;
+    P2T_REQUIRE(a.N % ((swiglu || rope) ? 64 : 16) == 0, "gemm_nt: N=%lld must be a multiple of %d", (long long)a.N, (swiglu || rope) ? 64 : 16);
+    P2T_REQUIRE(!rope || (a.cs && a.q && a.k && a.v && a.seq > 0 && a.N == (int64_t)(a.nh + 2 * a.nkv) * 64 && a.M % a.seq == 0),
+                "gemm_nt: EPI_QKV_ROPE needs head_dim 64 outputs, the rotary table and M = B * seq");
     P2T_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0 && a.lda >= a.K && a.ldw >= a.K,
                 "gemm_nt: K and the row strides must be multiples of 4 (K=%lld lda=%lld ldw=%lld ldc=%lld)", (long long)a.K,
                 (long long)a.lda, (long long)a.ldw, (long long)a.ldc);
     const int n_out = swiglu ? (int)a.N / 2 : (int)a.N;
-    P2T_REQUIRE(a.ldc >= n_out, "gemm_nt: ldc=%lld < %d output columns", (long long)a.ldc, n_out);
+    P2T_REQUIRE(rope || a.ldc >= n_out, "gemm_nt: ldc=%lld < %d output columns", (long long)a.ldc, n_out);
     int out_dtype = a.out_dtype;
     if (a.epilogue == P2T_EPI_RESID || a.epilogue == P2T_EPI_STORE_F32) out_dtype = P2T_F32;
     P2T_REQUIRE(a.epilogue != P2T_EPI_GELU_BWD || a.z, "gemm_nt: EPI_GELU_BWD needs z");
@@ -63,6 +66,7 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     ep.bias = a.bias; ep.out = a.out; ep.z = a.z; ep.ldc = a.ldc; ep.M = a.M; ep.N = (int)a.N; ep.n_zero = n_zero;
     ep.accumulate = a.accumulate; ep.drop_p = a.drop_p; ep.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     ep.drop_seed = a.drop_seed;
+    ep.cs = a.cs; ep.q = a.q; ep.k = a.k; ep.v = a.v; ep.seq = a.seq; ep.nh = a.nh; ep.nkv = a.nkv; ep.q_scale = a.q_scale;
 
     const bool aligned = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0);
     const bool can_mfma = a.dtype == P2T_BF16 && a.K % 64 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && aligned;
@@ -80,19 +84,19 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     return launch_gemm_simple(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, a.dtype, out_dtype, a.epilogue, ep, s);
 }
 
-int attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
-              int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal, int dtype,
-              int use_mfma, hipStream_t s) {
-    P2T_REQUIRE(q && k && vt && key_mask && kv_info && out && B > 0 && T > 0 && nh > 0 && nkv > 0, "attention: bad arguments");
+int attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+              int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype, int use_mfma,
+              hipStream_t s) {
+    P2T_REQUIRE(q && k && v && key_mask && kv_info && out && B > 0 && T > 0 && nh > 0 && nkv > 0, "attention: bad arguments");
     P2T_REQUIRE(ld_out >= (int64_t)nh * d, "attention: ld_out too small");
     if (dtype == P2T_BF16 && use_mfma != 0) {
         const int pi = prof_begin(s, 1, 4.0 * B * nh * (double)T * T * d * (causal ? 0.5 : 1.0));
-        const int rc = launch_attn_mfma(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, s);
+        const int rc = launch_attn_mfma(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, s);
         prof_end(s, pi);
         return rc;
     }
     P2T_REQUIRE(use_mfma != 1, "attention: MFMA kernel needs bf16");
-    return launch_attn_simple(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, dtype, s);
+    return launch_attn_simple(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, dtype, s);
 }
 
 }  // namespace p2t
@@ -133,17 +137,16 @@ extern "C" int p2t_mask_prepare(const int64_t* ids, const int64_t* mask, int B, 
 }
 
 extern "C" int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos_sin_scratch, void* q, void* k,
-                            void* vt, int B, int T, int nh, int nkv, int d, int dp, int tp, float q_scale, int dtype,
-                            p2t_stream stream) {
-    P2T_REQUIRE(qkv && inv_freq && cos_sin_scratch && q && k && vt, "p2t_qkv_post: bad arguments");
+                            void* v, int B, int T, int nh, int nkv, int d, int dp, float q_scale, int dtype, p2t_stream stream) {
+    P2T_REQUIRE(qkv && inv_freq && cos_sin_scratch && q && k && v, "p2t_qkv_post: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     P2T_TRY(launch_rope_table(inv_freq, T, d / 2, cos_sin_scratch, s));
-    return launch_qkv_post(qkv, ldq, cos_sin_scratch, q, k, vt, B, T, nh, nkv, d, dp, tp, q_scale, dtype, s);
+    return launch_qkv_post(qkv, ldq, cos_sin_scratch, q, k, v, B, T, nh, nkv, d, dp, q_scale, dtype, s);
 }
 
-extern "C" int p2t_attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info,
-                             void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale,
-                             int causal, int dtype, int use_mfma, p2t_stream stream) {
-    return attention(q, k, vt, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, tp, scale, causal, dtype, use_mfma,
+extern "C" int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
+                             void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
+                             int dtype, int use_mfma, p2t_stream stream) {
+    return attention(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, dtype, use_mfma,
                      (hipStream_t)stream);
 }

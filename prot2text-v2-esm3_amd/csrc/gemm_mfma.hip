@@ -1,20 +1,26 @@
 // bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T, fp32 accumulate, fused epilogue.
 //
-// Both operands are K-contiguous (activations [M][K], PyTorch Linear weights [N][K]), so A and W
-// tiles stage and read identically.  Structure (cdna_hip_programming.md section 5):
-//   * block tile BM x BN x 64, WM x WN wavefronts, each owning (MT*16) x (NT*16) outputs as
-//     v_mfma_f32_16x16x32_bf16 accumulators (the 16x16x32 shape holds the higher clock, microarch
-//     DVFS note 7);
-//   * global -> LDS by `global_load_lds_dwordx4` (no VGPR round trip), double-buffered;
-//     the LDS image is lane-linear, so the bank-conflict swizzle (16-B chunk c of row r stored at
-//     chunk c ^ (r & 7)) is applied to the per-lane SOURCE address and again on the ds_read_b128
-//     (rule 21) -- conflict-free for the 16x16x32 fragment read pattern;
-//   * operands are passed swapped (W fragment as MFMA "A", activation fragment as "B") so a lane
-//     ends up with 4 consecutive output COLUMNS of one row: vector bias loads, 8/16-byte stores,
-//     and the SwiGLU gate/up partner (+16 columns) in the same lane;
-//   * 1-D grid with an XCD-aware, grouped tile order: the 8 XCDs get contiguous chunks of the
-//     tile list and consecutive tiles share activation row-panels (L2 reuse, technique T1).
+// Both operands are K-contiguous (activations [M][K], PyTorch Linear weights [N][K]), so A and W tiles stage and
+// read identically.  Structure (chosen by in-process A/B runs of tools/gemm_lab.*, profiles/r01_gemm_lab.log):
+//   * block tile BM x 256 (BM = 256 or 128), 8 wavefronts as 2 (M) x 4 (N), each owning (BM/2) x 64 outputs as
+//     v_mfma_f32_16x16x32_bf16 accumulators;
+//   * K is consumed in 32-deep stages through a 4-slot LDS ring filled by `global_load_lds_dwordx4` (no VGPR
+//     round trip): three stages stay in flight across raw s_barriers behind counted `s_waitcnt vmcnt(N)`;
+//   * fragments are double-buffered in registers: the ds_read_b128 of stage s+1 and the DMA issue of stage s+4 are
+//     interleaved between the 32 MFMAs of stage s (sched_group_barrier), so the matrix pipe restarts right after
+//     each barrier instead of waiting out the LDS latency;
+//   * the LDS image is lane-linear, so the bank swizzle (64-byte rows: 16-B chunk c of row r stored at
+//     c ^ ((-(r >> 2)) & 3), conflict-free for the 16x16x32 fragment pattern) is applied to the per-lane SOURCE
+//     address and again on the ds_read (rule 21);
+//   * operands are passed swapped (W fragment as MFMA "A") and the W rows of each 64-row group are PERMUTED while
+//     staging (LDS row 16 i + 4 q + e  <-  weight row 32 (i >> 1) + 8 q + 4 (i & 1) + e), so a lane ends up with
+//     8 consecutive output columns of one row, twice (columns n..n+7 and n+32..n+39): 16-byte stores, vector bias
+//     loads, and the pairwise epilogues (SwiGLU gate/up, rotate-half RoPE partners) finish inside one lane;
+//   * 1-D grid with an XCD-aware, grouped tile order: the 8 XCDs get contiguous chunks of the tile list and
+//     consecutive tiles share activation row-panels (L2 reuse, technique T1).
 // Requirements: K % 64 == 0 (callers pad K with zeros), lda/ldw % 8 == 0, 16-byte aligned bases.
+#include <type_traits>
+
 #include "common.h"
 #include "epilogue.h"
 #include "kernels.h"
@@ -25,25 +31,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-template <int WM, int WN, int MT, int NT, typename Epi>
-__global__ void __launch_bounds__(WM* WN * 64)
+template <int MT, typename Epi>
+__global__ void __launch_bounds__(512)
     gemm_nt_mfma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M,
                         int N, int K, int tiles_m, int tiles_n, int n_cover, EpiParams ep) {
-    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, NTHREADS = WM * WN * 64;
-    constexpr int RPP = NTHREADS / 8;                       // rows staged per pass of all waves
-    constexpr int A_PASSES = BM / RPP, W_PASSES = BN / RPP;
-    constexpr int STAGE = (BM + BN) * 128;                  // bytes per K-tile (64 bf16 = 128 B per row)
-    static_assert(BM % RPP == 0 && BN % RPP == 0 && NT % 2 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int WN = 4, NT = 4, BM = 2 * MT * 16, BN = 256;
+    constexpr int AI = BM / 128;                            // A staging instructions per wave per stage (1 KiB each)
+    constexpr int SLOT = (BM + BN) * 64;                    // bytes per 32-deep stage
+    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
 
     // ---- tile coordinates: XCD chunking (bijective) + grouped (GM row-tiles) order ----
     const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     constexpr int GM = 4;
-    const int band = swz / (GM * tiles_n), first_m = band * GM;
+    const int band = swz_id / (GM * tiles_n), first_m = band * GM;
     const int gm = min(GM, tiles_m - first_m);
-    const int in_band = swz - band * GM * tiles_n;
+    const int in_band = swz_id - band * GM * tiles_n;
     const int tm = first_m + in_band % gm, tn = in_band / gm;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
@@ -52,40 +56,40 @@ __global__ void __launch_bounds__(WM* WN * 64)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / WN, wn = w % WN;
 
-    // ---- staging addresses: lane -> (row in pass, 16-B slot); source chunk = slot ^ (row & 7) ----
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
-    const bf16_t* a_src[A_PASSES];
-    const bf16_t* w_src[W_PASSES];
+    // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row = lane >> 2, slot = lane & 3) ----
+    const int schunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    const bf16_t* a_src[AI];
+    const bf16_t* w_src[2];
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-        int64_t row = m0 + i * RPP + w * 8 + srow;
-        row = row < M ? row : M - 1;
-        a_src[i] = A + row * lda + schunk * 8;
+    for (int t = 0; t < AI; ++t) {
+        int64_t am = m0 + (w * AI + t) * 16 + (lane >> 2);
+        am = am < M ? am : M - 1;
+        a_src[t] = A + am * lda + schunk * 8;
     }
 #pragma unroll
-    for (int i = 0; i < W_PASSES; ++i) {
-        int row = n0 + i * RPP + w * 8 + srow;
-        row = row < N ? row : N - 1;
-        w_src[i] = W + (int64_t)row * ldw + schunk * 8;
+    for (int t = 0; t < 2; ++t) {
+        const int R = (w * 2 + t) * 16 + (lane >> 2), r = R & 63;
+        const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);     // permuted weight row
+        int wr = n0 + (R & ~63) + nl;
+        wr = wr < N ? wr : N - 1;
+        w_src[t] = W + (int64_t)wr * ldw + schunk * 8;
     }
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE + w * 1024;
+    auto stage = [&](int s) {
+        char* base = smem + (s & 3) * SLOT;
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (int64_t)kt * 64), (lptr_t)(base + i * RPP * 128), 16, 0, 0);
+        for (int t = 0; t < AI; ++t)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[t] + (int64_t)s * 32), (lptr_t)(base + (w * AI + t) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < W_PASSES; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (int64_t)kt * 64),
-                                             (lptr_t)(base + BM * 128 + i * RPP * 128), 16, 0, 0);
+        for (int t = 0; t < 2; ++t)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[t] + (int64_t)s * 32), (lptr_t)(base + BM * 64 + (w * 2 + t) * 1024), 16, 0, 0);
     };
+    constexpr int NL = AI + 2;                              // DMA instructions per wave per stage
 
-    // ---- fragment read offsets (bytes within a stage) ----
+    // ---- fragment read offsets ----
     const int fr = lane & 15, kg = lane >> 4;
-    const int sw0 = ((0 * 4 + kg) ^ (fr & 7)) << 4;         // k-step 0 chunk, swizzled
-    const int sw1 = ((1 * 4 + kg) ^ (fr & 7)) << 4;         // k-step 1
-    const int x_off = (wm * MT * 16 + fr) * 128;
-    const int w_off = BM * 128 + (wn * NT * 16 + fr) * 128;
+    const int sw = (kg ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4;
+    const int x_off = (wm * MT * 16 + fr) * 64 + sw;
+    const int w_off = BM * 64 + (wn * NT * 16 + fr) * 64 + sw;
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -93,52 +97,99 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K >> 6;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();          // tile kt is in LDS for every wave; everyone is done reading the other buffer
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* sb = smem + (kt & 1) * STAGE;
+    const int ns = K >> 5;
+    auto load_frags = [&](int s, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
+        const char* sb = smem + (s & 3) * SLOT;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int sw = ks ? sw1 : sw0;
-            bf16x8 xf[MT], wf[NT];
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 1024);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 2048 + sw);
+        for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + x_off + j * 1024);
+    };
+    auto mfma_all = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + x_off + j * 2048 + sw);
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    };
+    // s_waitcnt vmcnt(n) only (lgkmcnt / expcnt untouched): simm16 = vmcnt[3:0] | 0x70 | 0xF00 | vmcnt[5:4] << 14
+    auto wait_vm = [&](int n_stages) {                      // n_stages of DMA (NL loads each) may remain in flight
+        if (n_stages >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((3 * NL) & 15) | (((3 * NL) >> 4) << 14));
+        else if (n_stages == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * NL) & 15) | (((2 * NL) >> 4) << 14));
+        else if (n_stages == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (NL & 15));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+    // one 32-deep stage: stage s+1 must have landed, its fragments and the DMA of stage s+4 are issued between the
+    // MFMAs of stage s.  FULL = steady state (stages s+1 .. s+4 exist): branch-free so the scheduler can interleave.
+    auto step = [&](auto full, int s, bf16x8 (&xc)[MT], bf16x8 (&wc)[NT], bf16x8 (&xn)[MT], bf16x8 (&wnx)[NT]) {
+        constexpr bool FULL = decltype(full)::value;
+        if (FULL) wait_vm(2);
+        else if (s + 1 < ns) wait_vm(min(ns - 1, s + 3) - (s + 1));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (FULL || s + 1 < ns) load_frags(s + 1, xn, wnx);
+        if (FULL || s + 4 < ns) stage(s + 4);
+        mfma_all(xc, wc);
+        if (FULL) {
+            constexpr int PER = (MT * NT) / (MT + NT + NL);              // MFMAs between two memory issues
 #pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            for (int qq = 0; qq < MT + NT; ++qq) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);    // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+            }
+#pragma unroll
+            for (int qq = 0; qq < NL; ++qq) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (LDS DMA)
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): exact counts at the back edge
+    };
+
+    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < ns) stage(s);
+    wait_vm(min(ns - 1, 3));                                            // stage 0 landed
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, xa, wa);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int s = 0;
+    for (; s + 5 < ns; s += 2) {
+        step(std::true_type{}, s, xa, wa, xb, wb);
+        step(std::true_type{}, s + 1, xb, wb, xa, wa);
+    }
+    for (; s < ns; s += 2) {
+        step(std::false_type{}, s, xa, wa, xb, wb);
+        step(std::false_type{}, s + 1, xb, wb, xa, wa);
     }
 
-    // ---- epilogue: lane owns row m, columns n .. n+3 of each 16x16 tile ----
-    const int ncol = n0 + wn * NT * 16 + kg * 4;
+    // ---- epilogue: lane owns row m, columns nb .. nb+7 (n-tiles 0,1) and nb+32 .. nb+39 (n-tiles 2,3) ----
+    const int nb = n0 + wn * 64 + kg * 8;
+    if (nb >= n_cover) return;
+    float b0[8], b1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b0[e] = b1[e] = 0.f;
+    if (ep.bias) {
+        if (nb < N) loadW<8>(ep.bias + nb, b0);
+        if (nb + 32 < N) loadW<8>(ep.bias + nb + 32, b1);
+    }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
         if (m >= M) continue;
-#pragma unroll
-        for (int i = 0; i < NT; i += 2) {
-            const int n = ncol + i * 16;
-            if (n >= n_cover) continue;
-            const float v0[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const float v1[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
-            Epi::apply2(ep, m, n, v0, v1);
-        }
+        const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+        const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+        Epi::template apply2<8>(ep, m, nb, v0, v1, b0, b1);
     }
 }
 
-template <int WM, int WN, int MT, int NT, typename Epi>
+template <int MT, typename Epi>
 static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                       const EpiParams& ep, hipStream_t s) {
-    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(n_cover, BN);
-    gemm_nt_mfma_kernel<WM, WN, MT, NT, Epi><<<dim3((unsigned)(tiles_m * tiles_n)), WM * WN * 64, 0, s>>>(
+    constexpr int BM = 2 * MT * 16;
+    const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(n_cover, 256);
+    gemm_nt_mfma_kernel<MT, Epi><<<dim3((unsigned)(tiles_m * tiles_n)), 512, 0, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tiles_m, tiles_n, n_cover, ep);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
@@ -147,11 +198,19 @@ static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, in
 template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                         const EpiParams& ep, int tile, hipStream_t s) {
-    // 256x256 fills the chip once there are >= ~256 tiles; otherwise 128x128 (2 blocks per CU).
-    const int64_t big_tiles = ceil_div(M, 256) * ceil_div(n_cover, 256);
-    if (tile == 256 || (tile == 0 && big_tiles >= 192))
-        return launch_cfg<2, 4, 8, 4, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
-    return launch_cfg<2, 2, 4, 4, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+    // 256 CUs, one block per CU: pick the row-tile height that needs the fewest "rounds" of the chip
+    // (a 128-row tile costs a little more than half a 256-row tile).
+    const int64_t tn = ceil_div(n_cover, 256);
+    const double cost256 = (double)ceil_div(ceil_div(M, 256) * tn, 256) * 2.0;
+    const double cost128 = (double)ceil_div(ceil_div(M, 128) * tn, 256) * 1.35;
+    static const int env_tile = [] {                       // experiments only: P2T_GEMM_TILE=128|256 forces a tile height
+        const char* e = getenv("P2T_GEMM_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (tile == 0) tile = env_tile;
+    if (tile == 256 || (tile == 0 && cost256 <= cost128))
+        return launch_cfg<8, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+    return launch_cfg<4, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
 }
 
 int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
@@ -174,6 +233,9 @@ int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int
         case P2T_EPI_GELU_BWD:
             return ob ? launch_shape<EpiGeluBwd<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
                       : launch_shape<EpiGeluBwd<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+        case P2T_EPI_QKV_ROPE:
+            return ob ? launch_shape<EpiQkvRope<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
+                      : launch_shape<EpiQkvRope<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
     }
     set_error("gemm: unknown epilogue %d", epilogue);
     return P2T_ERR_ARG;

@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) gemm_nt_simple_kernel(const T* __restrict
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int64_t m0 = (int64_t)blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
-    const int nl = (tx >> 2) * 32 + (tx & 3) * 4;          // first column group; partner at nl + 16
+    const int nl = (tx >> 3) * 64 + (tx & 7) * 4;          // first column group; partner at nl + 32 (epilogue.h)
     float acc0[4][4], acc1[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) gemm_nt_simple_kernel(const T* __restrict
             float av[4], b0[4], b1[4];
             load4(&As[kk][ty * 4], av);
             load4(&Ws[kk][nl], b0);
-            load4(&Ws[kk][nl + 16], b1);
+            load4(&Ws[kk][nl + 32], b1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -55,10 +55,16 @@ __global__ void __launch_bounds__(256) gemm_nt_simple_kernel(const T* __restrict
                 }
         }
     }
+    if (n0 + nl >= n_cover) return;
+    float bb0[4] = {0.f, 0.f, 0.f, 0.f}, bb1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias) {
+        if (n0 + nl < N) load4(ep.bias + n0 + nl, bb0);
+        if (n0 + nl + 32 < N) load4(ep.bias + n0 + nl + 32, bb1);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + ty * 4 + i;
-        if (m < M && n0 + nl < n_cover) Epi::apply2(ep, m, n0 + nl, acc0[i], acc1[i]);
+        if (m < M) Epi::template apply2<4>(ep, m, n0 + nl, acc0[i], acc1[i], bb0, bb1);
     }
 }
 
@@ -92,6 +98,9 @@ static int dispatch_epi(const void* A, int64_t lda, const void* W, int64_t ldw, 
         case P2T_EPI_GELU_BWD:
             return ob ? launch_simple_t<T, EpiGeluBwd<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
                       : launch_simple_t<T, EpiGeluBwd<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_QKV_ROPE:
+            return ob ? launch_simple_t<T, EpiQkvRope<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
+                      : launch_simple_t<T, EpiQkvRope<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
     }
     set_error("gemm: unknown epilogue %d", epilogue);
     return P2T_ERR_ARG;

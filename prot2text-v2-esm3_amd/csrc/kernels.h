@@ -6,7 +6,9 @@ namespace p2t {
 
 struct EpiParams;
 
-int launch_colsum(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate, hipStream_t s);
+size_t colsum_scratch_bytes(int64_t cols);
+int launch_colsum(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate, float* scratch,
+                  hipStream_t s);
 
 int launch_layernorm(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* y, int64_t ld_y,
                      int64_t rows, int64_t cols, int out_dtype, hipStream_t s);
@@ -23,8 +25,8 @@ int launch_llama_embed(const int64_t* ids, const void* table, int dtype, int H, 
 int launch_inv_freq(float* inv_freq, int half, float theta, int llama3, float factor, float low_ff, float high_ff,
                     float orig_max_pos, hipStream_t s);
 int launch_rope_table(const float* inv_freq, int T, int half, float* cs, hipStream_t s);
-int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* vt, int B, int T, int nh, int nkv,
-                    int d, int dp, int tp, float q_scale, int dtype, hipStream_t s);
+int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* v, int B, int T, int nh, int nkv,
+                    int d, int dp, float q_scale, int dtype, hipStream_t s);
 
 int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int dtype,
                        int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s);
@@ -36,19 +38,21 @@ struct GemmArgs {
     int64_t M; int64_t N; int64_t K; int dtype; int out_dtype; int epilogue; int accumulate; int use_mfma;
     int n_zero;                 // -1: default (next multiple of 64, clipped to ldc)
     float drop_p; uint64_t drop_seed;
-    int tile;                   // 0 auto, 128, 256
+    int tile;                   // 0 auto, 128, 256 (rows of the MFMA block tile)
+    // P2T_EPI_QKV_ROPE only (head_dim 64): rotary table [T, 64], outputs [B, heads, T, 64]
+    const float* cs = nullptr; void* q = nullptr; void* k = nullptr; void* v = nullptr;
+    int seq = 0, nh = 0, nkv = 0; float q_scale = 1.f;
 };
 int gemm_nt(const GemmArgs& a, hipStream_t s);
 
-int launch_attn_simple(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
-                       int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal, int dtype,
+int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+                       int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype,
                        hipStream_t s);
-int launch_attn_mfma(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
-                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal,
-                     hipStream_t s);
-int attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, const int32_t* kv_info, void* out,
-              int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, int tp, float scale, int causal, int dtype,
-              int use_mfma, hipStream_t s);
+int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, hipStream_t s);
+int attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
+              int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype, int use_mfma,
+              hipStream_t s);
 
 // adapter tail helpers (adapter.hip)
 int launch_adapter_dz2(const void* g2, const void* z2, const float* inv_norm, const float* dy, void* dz2, int64_t ld, int64_t M,

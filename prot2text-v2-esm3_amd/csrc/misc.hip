@@ -70,23 +70,34 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ sr
     }
 }
 
-// out[c] (+)= sum_r x[r, c]; one block per 64 columns, 4 waves stride the rows.
+
+// Column sums in two deterministic stages (no atomics): stage 1, grid (cols/64, kColsumChunks): each block sums its
+// row chunk of a 64-column slab (4 waves stride the rows) into partial[chunk][col]; stage 2 adds the chunks in order.
+constexpr int kColsumChunks = 64;
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
-                                                     float* __restrict__ out, int accumulate) {
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                             float* __restrict__ partial) {
     __shared__ float part[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
     float acc = 0.f;
     if (c < cols)
-        for (int64_t r = ty; r < rows; r += 4) acc += to_f32(x[r * ld + c]);
+        for (int64_t r = r0 + ty; r < r1; r += 4) acc += to_f32(x[r * ld + c]);
     part[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0 && c < cols) {
-        const float s = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
-        out[c] = accumulate ? out[c] + s : s;
-    }
+    if (ty == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
 }
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int chunks, int64_t cols,
+                                                           float* __restrict__ out, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
 
 // x[i] *= s[0]  (s lives on the device: chain-rule scaling without a host sync)
 __global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ s) {
@@ -100,13 +111,18 @@ static inline int stream_grid(int64_t n_items, int per_block) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+size_t colsum_scratch_bytes(int64_t cols) { return sizeof(float) * (size_t)kColsumChunks * (size_t)cols; }
+
 int launch_colsum(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate,
-                  hipStream_t s) {
-    const dim3 grid((unsigned)ceil_div(cols, 64));
+                  float* scratch, hipStream_t s) {
+    const int chunks = (int)(rows < kColsumChunks ? (rows < 1 ? 1 : rows) : kColsumChunks);
+    const dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)chunks);
     if (dtype == P2T_BF16)
-        colsum_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, rows, cols, ld, out, accumulate);
+        colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, rows, cols, ld, scratch);
     else
-        colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)x, rows, cols, ld, out, accumulate);
+        colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)x, rows, cols, ld, scratch);
+    P2T_LAUNCH_CHECK();
+    colsum_final_kernel<<<dim3((unsigned)ceil_div(cols, 256)), 256, 0, s>>>(scratch, chunks, cols, out, accumulate);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -14,13 +14,13 @@ namespace {
 
 struct EsmBuffers {
     uint8_t* key_mask; int32_t* kv_info; float* emb_scale; float* inv_freq; float* cs;
-    float* x; void* h; void* qkv; void* q; void* k; void* vt; void* ao; void* ffn;
+    float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* ffn;
 };
 
 size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b) {
     const size_t e = dtype_size(c->dtype);
     const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
-    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads;
+    const int d = c->head_dim, dp = head_dim_padded(d), nh = c->heads;
     Arena local(nullptr, ~(size_t)0 >> 1);
     Arena& a = ar ? *ar : local;
     EsmBuffers t;
@@ -34,7 +34,7 @@ size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b
     t.qkv = a.take(e * (size_t)M * 3 * H);
     t.q = a.take(e * (size_t)B * nh * T * dp);
     t.k = a.take(e * (size_t)B * nh * T * dp);
-    t.vt = a.take(e * (size_t)B * nh * dp * tp);
+    t.v = a.take(e * (size_t)B * nh * T * dp);
     t.ao = a.take(e * (size_t)M * Hp);
     t.ffn = a.take(e * (size_t)M * Fp);
     if (b) *b = t;
@@ -43,13 +43,13 @@ size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b
 
 struct LlamaBuffers {
     uint8_t* key_mask; int32_t* kv_info; float* inv_freq; float* cs;
-    float* x; void* h; void* qkv; void* q; void* k; void* vt; void* ao; void* act;
+    float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* act;
 };
 
 size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffers* b) {
     const size_t e = dtype_size(c->dtype);
     const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
-    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads, nkv = c->kv_heads;
+    const int d = c->head_dim, dp = head_dim_padded(d), nh = c->heads, nkv = c->kv_heads;
     const int64_t QO = round_up((int64_t)nh * d, 64);
     Arena local(nullptr, ~(size_t)0 >> 1);
     Arena& a = ar ? *ar : local;
@@ -63,7 +63,7 @@ size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffe
     t.qkv = a.take(e * (size_t)M * (nh + 2 * nkv) * d);
     t.q = a.take(e * (size_t)B * nh * T * dp);
     t.k = a.take(e * (size_t)B * nkv * T * dp);
-    t.vt = a.take(e * (size_t)B * nkv * dp * tp);
+    t.v = a.take(e * (size_t)B * nkv * T * dp);
     t.ao = a.take(e * (size_t)M * QO);
     t.act = a.take(e * (size_t)M * Fp);
     if (b) *b = t;
@@ -94,7 +94,7 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
     P2T_REQUIRE(!ar.overflow, "p2t_esm2_forward: workspace overflow");
     const int dt = c->dtype;
     const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
-    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads;
+    const int d = c->head_dim, dp = head_dim_padded(d), nh = c->heads;
 
     P2T_TRY(launch_mask_prepare(ids, mask, B, T, c->mask_id, c->token_dropout, b.key_mask, b.kv_info, b.emb_scale, s));
     P2T_TRY(launch_esm_embed(ids, mask, w->word_emb, dt, b.emb_scale, T, (int)H, c->vocab, c->mask_id, c->token_dropout, b.x, M, s));
@@ -113,10 +113,17 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
     for (int l = 0; l < c->n_layers; ++l) {
         const p2t_esm2_layer& L = w->layers[l];
         P2T_TRY(launch_layernorm(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
-        GemmArgs g1{b.h, Hp, L.qkv_w, Hp, L.qkv_b, b.qkv, 3 * H, nullptr, M, 3 * H, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)(3 * H), 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g1, s));
-        P2T_TRY(launch_qkv_post(b.qkv, 3 * H, b.cs, b.q, b.k, b.vt, B, T, nh, nh, d, dp, tp, q_scale, dt, s));
-        P2T_TRY(attention(b.q, b.k, b.vt, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, tp, 1.0f, 0, dt, -1, s));
+        if (d == 64) {
+            // QKV projection with bias + q-scale + rotary + head split fused into the GEMM epilogue
+            GemmArgs g1{b.h, Hp, L.qkv_w, Hp, L.qkv_b, nullptr, 0, nullptr, M, 3 * H, Hp, dt, dt, P2T_EPI_QKV_ROPE, 0, -1, -1, 0.f, 0, 0};
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nh; g1.q_scale = q_scale;
+            P2T_TRY(gemm_nt(g1, s));
+        } else {
+            GemmArgs g1{b.h, Hp, L.qkv_w, Hp, L.qkv_b, b.qkv, 3 * H, nullptr, M, 3 * H, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)(3 * H), 0.f, 0, 0};
+            P2T_TRY(gemm_nt(g1, s));
+            P2T_TRY(launch_qkv_post(b.qkv, 3 * H, b.cs, b.q, b.k, b.v, B, T, nh, nh, d, dp, q_scale, dt, s));
+        }
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, s));
         GemmArgs g2{b.ao, Hp, L.o_w, Hp, L.o_b, b.x, H, nullptr, M, H, Hp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g2, s));
         P2T_TRY(launch_layernorm(b.x, H, L.ln2_w, L.ln2_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
@@ -138,7 +145,7 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
                                         size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(c && w && ids && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
     P2T_REQUIRE(k >= 0 && k <= c->n_layers, "p2t_llama_hidden_forward: hidden_states[%d] out of range for %d layers", k, c->n_layers);
-    P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 16 == 0,
+    P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 32 == 0,
                 "p2t_llama_hidden_forward: unsupported shape");
     P2T_REQUIRE(w->embed && (k == 0 || w->layers) && (k < c->n_layers || w->final_norm_w), "p2t_llama_hidden_forward: missing weights");
     P2T_REQUIRE(workspace_bytes >= p2t_llama_workspace_bytes(c, B, T), "p2t_llama_hidden_forward: workspace too small");
@@ -149,7 +156,7 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
     P2T_REQUIRE(!ar.overflow, "p2t_llama_hidden_forward: workspace overflow");
     const int dt = c->dtype;
     const int64_t M = (int64_t)B * T, H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
-    const int d = c->head_dim, dp = head_dim_padded(d), tp = (int)round_up(T, 64), nh = c->heads, nkv = c->kv_heads;
+    const int d = c->head_dim, dp = head_dim_padded(d), nh = c->heads, nkv = c->kv_heads;
     const int64_t NQKV = (int64_t)(nh + 2 * nkv) * d, QO = round_up((int64_t)nh * d, 64);
 
     P2T_TRY(launch_mask_prepare(nullptr, mask, B, T, -1, 0, b.key_mask, b.kv_info, nullptr, s));
@@ -165,10 +172,16 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
     for (int l = 0; l < k; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
-        GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g1, s));
-        P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.vt, B, T, nh, nkv, d, dp, tp, 1.0f, dt, s));
-        P2T_TRY(attention(b.q, b.k, b.vt, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, tp, scale, 1, dt, -1, s));
+        if (d == 64) {
+            GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, nullptr, 0, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_QKV_ROPE, 0, -1, -1, 0.f, 0, 0};
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f;
+            P2T_TRY(gemm_nt(g1, s));
+        } else {
+            GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
+            P2T_TRY(gemm_nt(g1, s));
+            P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, 1.0f, dt, s));
+        }
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, s));
         GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g2, s));
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));

@@ -385,8 +385,8 @@ class LlamaTextModel(nn.Module):
     def _build_engine(self, n_layers: int):
         s, dt = self.spec, self.dtype
         H, F, d = s.hidden_size, s.intermediate_size, s.head_dim
-        if F % 16:
-            raise ValueError("Llama intermediate_size must be a multiple of 16")
+        if F % 32:
+            raise ValueError("Llama intermediate_size must be a multiple of 32")
         Hp, Fp, QO = round_up(H, 64), round_up(F, 64), round_up(s.num_attention_heads * d, 64)
         keep, layers = [], (_lib.LlamaLayerC * max(n_layers, 1))()
         P = dict(self.named_parameters())
@@ -394,7 +394,7 @@ class LlamaTextModel(nn.Module):
             p = f"layers.{i}."
             qkv = torch.cat([P[p + f"self_attn.{n}_proj.weight"].detach() for n in ("q", "k", "v")], 0)
             gate, up = P[p + "mlp.gate_proj.weight"].detach(), P[p + "mlp.up_proj.weight"].detach()
-            gu = torch.stack([gate.view(F // 16, 16, H), up.view(F // 16, 16, H)], 1).reshape(2 * F, H)
+            gu = torch.stack([gate.view(F // 32, 32, H), up.view(F // 32, 32, H)], 1).reshape(2 * F, H)   # 32-row gate/up blocks
             t = dict(qkv_w=_pad_cols(qkv, Hp, dt), o_w=_pad_cols(P[p + "self_attn.o_proj.weight"], QO, dt),
                      gu_w=_pad_cols(gu, Hp, dt), down_w=_pad_cols(P[p + "mlp.down_proj.weight"], Fp, dt),
                      ln1_w=_f32(P[p + "input_layernorm.weight"]), ln2_w=_f32(P[p + "post_attention_layernorm.weight"]))

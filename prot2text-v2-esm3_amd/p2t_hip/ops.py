@@ -125,23 +125,23 @@ def mask_prepare(mask: torch.Tensor, ids: torch.Tensor | None = None, mask_id: i
 
 
 def qkv_post(qkv: torch.Tensor, inv_freq: torch.Tensor, B: int, T: int, nh: int, nkv: int, d: int, q_scale: float):
-    dp, tp = head_dim_padded(d), round_up(T, 64)
+    dp = head_dim_padded(d)
     dev, dty = qkv.device, qkv.dtype
     q = torch.empty((B, nh, T, dp), dtype=dty, device=dev)
     k = torch.empty((B, nkv, T, dp), dtype=dty, device=dev)
-    vt = torch.empty((B, nkv, dp, tp), dtype=dty, device=dev)
+    v = torch.empty((B, nkv, T, dp), dtype=dty, device=dev)
     cs = torch.empty((T, d), dtype=torch.float32, device=dev)
-    call("p2t_qkv_post", ptr(qkv), qkv.stride(0), ptr(inv_freq), ptr(cs), ptr(q), ptr(k), ptr(vt), B, T, nh, nkv, d, dp, tp,
+    call("p2t_qkv_post", ptr(qkv), qkv.stride(0), ptr(inv_freq), ptr(cs), ptr(q), ptr(k), ptr(v), B, T, nh, nkv, d, dp,
          float(q_scale), dt_of(qkv), stream())
-    return q, k, vt
+    return q, k, v
 
 
-def attention(q, k, vt, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1):
+def attention(q, k, v, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1):
     B, nh, T, dp = q.shape
-    nkv, tp = k.shape[1], vt.shape[3]
+    nkv = k.shape[1]
     ld = round_up(nh * d, 64)
     out = torch.empty((B * T, ld), dtype=q.dtype, device=q.device)
-    call("p2t_attention", ptr(q), ptr(k), ptr(vt), ptr(key_mask), ptr(kv_info), ptr(out), ld, B, T, nh, nkv, d, dp, tp,
+    call("p2t_attention", ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(kv_info), ptr(out), ld, B, T, nh, nkv, d, dp,
          float(scale), int(causal), dt_of(q), use_mfma, stream())
     return out
 

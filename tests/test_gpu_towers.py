@@ -157,13 +157,18 @@ def test_cfg1_fp32_vs_reference_golden(golden):
         assert rel(got, g[f"grad_seg2_{n}"]) < 2e-3, n
 
 
-def test_bf16_mfma_step_matches_fp32_path_at_size():
+@pytest.mark.parametrize("esm_kind", ["t12_35M_d24", "d64_fused_rope"])
+def test_bf16_mfma_step_matches_fp32_path_at_size(esm_kind):
     """Size-independent cross-check at a shape the CPU oracle cannot reach quickly: the bf16 MFMA
-    pipeline against the exact fp32-FMA pipeline on the same synthetic model (esm2_t12_35M-shaped
-    towers, head_dim 24, ragged batch)."""
+    pipeline against the exact fp32-FMA pipeline on the same synthetic model (ragged batch).
+    t12_35M_d24: esm2_t12_35M-shaped encoder (H = 480 -> K padding, head_dim 24 -> unfused rotary pass);
+    d64_fused_rope: head_dim 64 encoder (QKV GEMM with the fused bias + scale + rotary + head-split epilogue)."""
     import p2t_hip as P
     from p2t_hip import specs, synth
-    esm = specs.esm_spec("esm2_t12_35M", num_hidden_layers=4)
+    if esm_kind == "t12_35M_d24":
+        esm = specs.esm_spec("esm2_t12_35M", num_hidden_layers=4)
+    else:
+        esm = specs.EsmSpec(num_hidden_layers=3, hidden_size=512, intermediate_size=1536, num_attention_heads=8)
     llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=512, intermediate_size=1408, num_attention_heads=8,
                             num_key_value_heads=2, vocab_size=1024)
     ad = specs.AdapterSpec(esm.hidden_size, 256, llama.hidden_size, 0.0)

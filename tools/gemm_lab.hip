@@ -1,0 +1,404 @@
+// GEMM laboratory (NOT product code): kernel variants of C = A W^T (bf16, fp32 accumulate, bf16 out + bias)
+// timed with HIP events in one process for A/B decisions (cdna_hip_programming.md 5.4 rule 24).
+// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC tools/gemm_lab.hip -o gpurun_out/libgemm_lab.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+struct TileMap {
+    int tm, tn;
+    __device__ TileMap(int tiles_m, int tiles_n) {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+        const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+        constexpr int GM = 4;
+        const int band = swz / (GM * tiles_n), first_m = band * GM;
+        const int gm = min(GM, tiles_m - first_m);
+        const int in_band = swz - band * GM * tiles_n;
+        tm = first_m + in_band % gm;
+        tn = in_band / gm;
+    }
+};
+
+// ABL bit0: skip epilogue stores; bit1: no global loads after the prologue; bit2: skip MFMA
+// VAR 0: baseline (current product structure).  VAR 1: register double-buffered fragments, barrier mid-tile.
+// VAR 2: VAR 1 + s_setprio around MFMA groups.
+template <int VAR, int ABL>
+__global__ void __launch_bounds__(512) lab_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                  int64_t ldw, const float* __restrict__ bias, bf16_t* __restrict__ C,
+                                                  int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int WM = 2, WN = 4, MT = 8, NT = 4;
+    constexpr int BM = 256, BN = 256, RPP = 64, A_PASSES = 4, W_PASSES = 4, STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const TileMap tmap(tiles_m, tiles_n);
+    const int64_t m0 = (int64_t)tmap.tm * BM;
+    const int n0 = tmap.tn * BN;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / WN, wn = w % WN;
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const bf16_t* a_src[A_PASSES];
+    const bf16_t* w_src[W_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        int64_t row = m0 + i * RPP + w * 8 + srow;
+        row = row < M ? row : M - 1;
+        a_src[i] = A + row * lda + schunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PASSES; ++i) {
+        int row = n0 + i * RPP + w * 8 + srow;
+        row = row < N ? row : N - 1;
+        w_src[i] = W + (int64_t)row * ldw + schunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE + w * 1024;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (int64_t)kt * 64), (lptr_t)(base + i * RPP * 128), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (int64_t)kt * 64), (lptr_t)(base + BM * 128 + i * RPP * 128), 16, 0, 0);
+    };
+    const int fr = lane & 15, kg = lane >> 4;
+    const int sw0 = ((0 * 4 + kg) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + kg) ^ (fr & 7)) << 4;
+    const int x_off = (wm * MT * 16 + fr) * 128;
+    const int w_off = BM * 128 + (wn * NT * 16 + fr) * 128;
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = K >> 6;
+
+    auto load_frags = [&](const char* sb, int sw, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 2048 + sw);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + x_off + j * 2048 + sw);
+    };
+    auto mfma_all = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+        if (ABL & 4) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(xf[j]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[j]));
+            return;
+        }
+        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (VAR == 0) {
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk && !((ABL & 2) && kt >= 1)) stage((kt + 1) & 1, kt + 1);
+            const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[MT], wf[NT];
+                load_frags(sb, ks ? sw1 : sw0, xf, wf);
+                mfma_all(xf, wf);
+            }
+        }
+    } else {
+        bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(smem, sw0, xa, wa);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): scoreboard clean at the loop head
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sb = smem + (kt & 1) * STAGE;
+            load_frags(sb, sw1, xb, wb);                      // k-step 1 fragments fly under the k-step 0 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_all(xa, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): tile kt+1 landed, our reads of this buffer done
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) load_frags(smem + ((kt + 1) & 1) * STAGE, sw0, xa, wa);   // next tile's k-step 0 under the k-step 1 MFMAs
+            if (kt + 2 < nk && !(ABL & 2)) stage(kt & 1, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_all(xb, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0) before the back edge (keeps the compiler's counts exact)
+        }
+    }
+
+    // epilogue: bias preloaded as float4 per n-tile, rows m in-bounds checked once per tile row
+    if (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    const int ncol = n0 + wn * NT * 16 + kg * 4;
+    float4 bv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = ncol + i * 16;
+        bv[i] = (bias && n < N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
+        if (m >= M) continue;
+        bf16_t* crow = C + m * ldc;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = ncol + i * 16;
+            if (n < N) {
+                const f32x4 v = acc[i][j];
+                *reinterpret_cast<uint2*>(crow + n) = make_uint2(pack2(v[0] + bv[i].x, v[1] + bv[i].y), pack2(v[2] + bv[i].z, v[3] + bv[i].w));
+            }
+        }
+    }
+}
+
+template <int VAR, int ABL>
+static float run(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int M, int N,
+                 int K, int iters, hipStream_t s) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i)
+        lab_kernel<VAR, ABL><<<tiles_m * tiles_n, 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, tiles_m, tiles_n);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i)
+        lab_kernel<VAR, ABL><<<tiles_m * tiles_n, 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, tiles_m, tiles_n);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? ms / iters : -1.f;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// VAR 3: 256x256 tile, BK=32 stages in a 4-slot LDS ring (3 stages of global_load_lds in flight behind counted
+// vmcnt + raw s_barrier), register double-buffered fragments, W rows permuted at staging time so a lane ends up
+// with 8 consecutive output columns (16-byte bf16 stores), bias preloaded.
+template <int ABL>
+__global__ void __launch_bounds__(512) lab_kernel3(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                   int64_t ldw, const float* __restrict__ bias, bf16_t* __restrict__ C,
+                                                   int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int WN = 4, MT = 8, NT = 4, BM = 256, SLOT = 512 * 64;      // 32 KiB per stage
+    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+    const TileMap tmap(tiles_m, tiles_n);
+    const int64_t m0 = (int64_t)tmap.tm * BM;
+    const int n0 = tmap.tn * 256;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / WN, wn = w % WN;
+    // staging: instruction ii in [0,16) of an operand covers LDS rows 16 ii .. 16 ii + 15 (64 B each)
+    const int hq = (4 - ((lane >> 4) & 3)) & 3;                 // h[(row >> 2) & 3], row & 15 = lane >> 2
+    const int schunk = (lane & 3) ^ hq;
+    const bf16_t* a_src[2];
+    const bf16_t* w_src[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int R = (w * 2 + t) * 16 + (lane >> 2);           // LDS row within the operand tile
+        int64_t am = m0 + R;
+        am = am < M ? am : M - 1;
+        a_src[t] = A + am * lda + schunk * 8;
+        const int r = R & 63;
+        const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);   // permuted W row
+        int wnr = n0 + (R & ~63) + nl;
+        wnr = wnr < N ? wnr : N - 1;
+        w_src[t] = W + (int64_t)wnr * ldw + schunk * 8;
+    }
+    auto stage = [&](int s) {
+        char* base = smem + (s & 3) * SLOT + w * 2048;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[t] + (int64_t)s * 32), (lptr_t)(base + t * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[t] + (int64_t)s * 32), (lptr_t)(base + 256 * 64 + t * 1024), 16, 0, 0);
+    };
+    const int fr = lane & 15, kg = lane >> 4;
+    const int swz = (kg ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4;
+    const int x_off = (wm * MT * 16 + fr) * 64 + swz;
+    const int w_off = 256 * 64 + (wn * NT * 16 + fr) * 64 + swz;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ns = K >> 5;
+    auto load_frags = [&](int s, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
+        const char* sb = smem + (s & 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 1024);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + x_off + j * 1024);
+    };
+    auto mfma_all = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+        if (ABL & 4) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(xf[j]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[j]));
+            return;
+        }
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+    };
+    // wait until stage s+1 has landed: stages s+2, s+3 (those that exist) may stay in flight
+    auto wait_next = [&](int s) {
+        const int rem = min(ns - 1, s + 3) - (s + 1);
+        if (rem >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
+        else if (rem == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+    };
+    auto step = [&](auto full, int s, bf16x8 (&xc)[MT], bf16x8 (&wc)[NT], bf16x8 (&xn)[MT], bf16x8 (&wn_)[NT]) {
+        constexpr bool FULL = decltype(full)::value;      // steady state: stages s+1 .. s+4 all exist, no branches
+        if (FULL) __builtin_amdgcn_s_waitcnt(0x0F78);
+        else if (s + 1 < ns) wait_next(s);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (FULL || s + 1 < ns) load_frags(s + 1, xn, wn_);
+        if ((FULL || s + 4 < ns) && !(ABL & 2)) stage(s + 4);
+        if (!(ABL & 8)) __builtin_amdgcn_sched_barrier(0);
+        mfma_all(xc, wc);
+        if ((ABL & 8) && FULL) {      // interleave: MFMAs start right after the barrier, one LDS read / DMA issue per 2 MFMAs
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+    };
+    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < ns) stage(s);
+    {   // stage 0 landed: stages 1..min(3, ns-1) may stay in flight
+        const int rem = min(ns - 1, 3);
+        if (rem >= 3) __builtin_amdgcn_s_waitcnt(0x0F7C);        // vmcnt(12)
+        else if (rem == 2) __builtin_amdgcn_s_waitcnt(0x0F78);
+        else if (rem == 1) __builtin_amdgcn_s_waitcnt(0x0F74);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, xa, wa);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int s = 0;
+    for (; s + 5 < ns; s += 2) {
+        step(std::true_type{}, s, xa, wa, xb, wb);
+        step(std::true_type{}, s + 1, xb, wb, xa, wa);
+    }
+    for (; s < ns; s += 2) {
+        step(std::false_type{}, s, xa, wa, xb, wb);
+        step(std::false_type{}, s + 1, xb, wb, xa, wa);
+    }
+    if (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // epilogue: lane owns, per row m, columns nb + 8 kg .. +7 (acc n-tiles 0,1) and nb + 32 + 8 kg .. +7 (n-tiles 2,3)
+    const int nb = n0 + wn * 64 + kg * 8;
+    float bv[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = nb + h * 32;
+        if (bias && n < N) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+            bv[h][0] = b0.x; bv[h][1] = b0.y; bv[h][2] = b0.z; bv[h][3] = b0.w;
+            bv[h][4] = b1.x; bv[h][5] = b1.y; bv[h][6] = b1.z; bv[h][7] = b1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[h][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
+        if (m >= M) continue;
+        bf16_t* crow = C + m * ldc;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = nb + h * 32;
+            if (n < N) {
+                const f32x4 v0 = acc[2 * h][j], v1 = acc[2 * h + 1][j];
+                *reinterpret_cast<uint4*>(crow + n) =
+                    make_uint4(pack2(v0[0] + bv[h][0], v0[1] + bv[h][1]), pack2(v0[2] + bv[h][2], v0[3] + bv[h][3]),
+                               pack2(v1[0] + bv[h][4], v1[1] + bv[h][5]), pack2(v1[2] + bv[h][6], v1[3] + bv[h][7]));
+            }
+        }
+    }
+}
+
+template <int ABL>
+static float run3(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int M, int N,
+                  int K, int iters, hipStream_t s) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i)
+        lab_kernel3<ABL><<<tiles_m * tiles_n, 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, tiles_m, tiles_n);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i)
+        lab_kernel3<ABL><<<tiles_m * tiles_n, 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, tiles_m, tiles_n);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? ms / iters : -1.f;
+}
+
+extern "C" float lab_gemm(int var, int abl, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                          int64_t ldc, int M, int N, int K, int iters, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CASE(V, B) if (var == V && abl == B) return run<V, B>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s)
+    CASE(0, 0); CASE(0, 1); CASE(0, 2); CASE(0, 4); CASE(0, 3);
+    CASE(1, 0); CASE(1, 1); CASE(1, 2); CASE(1, 4); CASE(1, 3);
+    CASE(2, 0); CASE(2, 1);
+    if (var == 3 && abl == 0) return run3<0>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 1) return run3<1>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 2) return run3<2>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 4) return run3<4>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 8) return run3<8>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 9) return run3<9>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+#undef CASE
+    return -2.f;
+}

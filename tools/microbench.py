@@ -54,9 +54,9 @@ def bench_attn():
         inv = torch.ones((d // 2,), dtype=torch.float32, device=dev)
         mask = torch.ones((B, T), dtype=torch.int64, device=dev)
         km, kv, _ = ops.mask_prepare(mask)
-        q, k, vt = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0)
+        q, k, v = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0)
         ms_post = timeit(lambda: ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0))
-        ms = timeit(lambda: ops.attention(q, k, vt, km, kv, d, d ** -0.5, causal, use_mfma=1))
+        ms = timeit(lambda: ops.attention(q, k, v, km, kv, d, d ** -0.5, causal, use_mfma=1))
         fl = 4.0 * B * nh * T * T * d * (0.5 if causal else 1.0)
         print(f"attn {name:8s} B={B} T={T} nh={nh}/{nkv} d={d}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s | qkv_post {ms_post:7.3f} ms", flush=True)
 
