@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--segments", type=int, default=1, help="contrastive_num_segments")
     ap.add_argument("--eval-mode", action="store_true", help="no adapter dropout (default: train mode, p=0.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="text tower and encoder segments on separate HIP streams (+1-3 %% throughput; per-kernel event times "
+                         "then include co-running kernels, so the roofline block is only meaningful without it)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="pairs in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -100,6 +103,20 @@ def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs):
                       f"{cores} BLAS threads, {work:.1f} s of CPU work (+{W.fetch_s:.1f} s downloading the GPU model's weights, excluded)"}
 
 
+def pmc_traffic(cfg_name, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, MI355X_MICROARCH.md HBM section); counters cannot be read from inside the benchmark process, so the
+    figure is only reported for the workload the passes were taken on, else null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if cfg_name != "cfg3" or batch != 16 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return round(json.load(f)["kernels"]["gemm_nt_mfma_kernel"]["hbm_bytes_per_launch"])
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     import torch
@@ -127,7 +144,8 @@ def main():
     model = P.Esm2LlamaInstructForCausalLM.from_specs(esm, llama, ad, dtype=dtype, device=dev, seed=0)
     model.esm_encoder.requires_grad_(False)
     model.llama_decoder.requires_grad_(False)
-    trainer = P.ContrastiveTrainer(model, num_segments=args.segments, train_mode=not args.eval_mode, global_negatives=True)
+    trainer = P.ContrastiveTrainer(model, num_segments=args.segments, train_mode=not args.eval_mode, global_negatives=True,
+                                  overlap_streams=args.overlap)
 
     pid, pmask = synth.protein_batch(1234 + rank, B, Tp)
     tid, tmask = synth.text_batch(1234 + rank, B, Tt)
@@ -185,7 +203,7 @@ def main():
                        "loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_mfma_kernel (bf16 16x16x32 MFMA GEMM, all epilogues)",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(args.config, B),
                          "launches_per_step": round(launches_step, 1), "avg_launch_ms": round(avg_ms, 4),
                          "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attention_ms_per_step": round(ms[1] / args.steps, 3),
                          "attention_tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1)},

@@ -31,26 +31,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-template <int MT, typename Epi>
-__global__ void __launch_bounds__(512)
-    gemm_nt_mfma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M,
-                        int N, int K, int tiles_m, int tiles_n, int n_cover, EpiParams ep) {
-    constexpr int WN = 4, NT = 4, BM = 2 * MT * 16, BN = 256;
-    constexpr int AI = BM / 128;                            // A staging instructions per wave per stage (1 KiB each)
-    constexpr int SLOT = (BM + BN) * 64;                    // bytes per 32-deep stage
-    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
-
-    // ---- tile coordinates: XCD chunking (bijective) + grouped (GM row-tiles) order ----
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int swz_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+// (tm, tn) of work item `id` out of `n_items`: the 8 XCDs get contiguous chunks (bijective for any count),
+// inside a chunk GM row-tiles are walked column-major so neighbouring CUs share activation panels.
+__device__ __forceinline__ void tile_coords(int id, int n_items, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q8 = n_items >> 3, r8 = n_items & 7, xcd = id & 7;
+    const int swz_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
     constexpr int GM = 4;
     const int band = swz_id / (GM * tiles_n), first_m = band * GM;
     const int gm = min(GM, tiles_m - first_m);
     const int in_band = swz_id - band * GM * tiles_n;
-    const int tm = first_m + in_band % gm, tn = in_band / gm;
-    const int64_t m0 = (int64_t)tm * BM;
-    const int n0 = tn * BN;
+    tm = first_m + in_band % gm;
+    tn = in_band / gm;
+}
+
+// One BM x 256 output tile at (m0, n0).  smem: 4 * (BM + 256) * 64 bytes.
+template <int MT, typename Epi>
+__device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                          int64_t ldw, int64_t M, int N, int K, int64_t m0, int n0, int n_cover,
+                                          const EpiParams& ep) {
+    constexpr int WN = 4, NT = 4, BM = 2 * MT * 16, BN = 256;
+    constexpr int AI = BM / 128;                            // A staging instructions per wave per stage (1 KiB each)
+    constexpr int SLOT = (BM + BN) * 64;                    // bytes per 32-deep stage
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,6 +186,17 @@ __global__ void __launch_bounds__(512)
 }
 
 template <int MT, typename Epi>
+__global__ void __launch_bounds__(512)
+    gemm_nt_mfma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M,
+                        int N, int K, int tiles_m, int tiles_n, int n_cover, EpiParams ep) {
+    constexpr int BM = 2 * MT * 16;
+    __shared__ __attribute__((aligned(16))) char smem[4 * (BM + 256) * 64];
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+    gemm_tile<MT, Epi>(smem, A, lda, W, ldw, M, N, K, (int64_t)tm * BM, tn * 256, n_cover, ep);
+}
+
+template <int MT, typename Epi>
 static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                       const EpiParams& ep, hipStream_t s) {
     constexpr int BM = 2 * MT * 16;
@@ -195,20 +207,24 @@ static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, in
     return P2T_OK;
 }
 
+// measured (profiles/r01_microbench_v2.log): a 128-row tile takes ~0.62 of a 256-row tile.  A mixed grid (whole
+// rounds of 256-row tiles + the leftover rows as 128-row tiles) was tried against the 2.5-round N = 2560 GEMMs and
+// measured 5-13 % SLOWER than plain 256-row tiles, so it is not used.
+constexpr double kSmallTileCost = 0.625;
+constexpr int kCUs = 256;
+
 template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                         const EpiParams& ep, int tile, hipStream_t s) {
-    // 256 CUs, one block per CU: pick the row-tile height that needs the fewest "rounds" of the chip
-    // (a 128-row tile costs a little more than half a 256-row tile).
-    const int64_t tn = ceil_div(n_cover, 256);
-    const double cost256 = (double)ceil_div(ceil_div(M, 256) * tn, 256) * 2.0;
-    const double cost128 = (double)ceil_div(ceil_div(M, 128) * tn, 256) * 1.35;
     static const int env_tile = [] {                       // experiments only: P2T_GEMM_TILE=128|256 forces a tile height
         const char* e = getenv("P2T_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
     if (tile == 0) tile = env_tile;
-    if (tile == 256 || (tile == 0 && cost256 <= cost128))
+    const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
+    const double cost256 = (double)ceil_div(tm256 * tn, kCUs);
+    const double cost128 = (double)ceil_div(tm128 * tn, kCUs) * kSmallTileCost * 1.08;
+    if (tile == 256 || (tile != 128 && cost256 <= cost128))
         return launch_cfg<8, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
     return launch_cfg<4, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
 }

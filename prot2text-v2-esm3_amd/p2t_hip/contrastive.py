@@ -221,13 +221,15 @@ class ContrastiveTrainer:
 
     def __init__(self, model, *, lr=2e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=None,
                  num_segments: int = 1, output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
-                 temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None):
+                 temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None,
+                 overlap_streams: bool = False):
         self.model = model
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                        max_norm=math.inf if max_norm is None else max_norm)
         self.num_segments, self.layer, self.readout_fn = num_segments, output_llm_layer, readout_fn
         self.ones_mask, self.temperature, self.train_mode = ones_mask, temperature, train_mode
         self.global_negatives, self.group = global_negatives, process_group
+        self.overlap_streams, self._streams = overlap_streams, {}
         self.step_count = 0
         ad = model.adapter
         c = ad.config
@@ -280,6 +282,11 @@ class ContrastiveTrainer:
             self._buf[key] = b
         return b
 
+    def _stream(self, i: int) -> "torch.cuda.Stream":
+        if i not in self._streams:
+            self._streams[i] = torch.cuda.Stream(device=self.dev)
+        return self._streams[i]
+
     def text_embeddings(self, tid, tmask) -> torch.Tensor:
         hs = self.model.llama_decoder.model.hidden_state(tid, tmask, self.layer)
         return ops.l2norm_rows(ops.readout(hs, tmask, self.readout_fn))
@@ -290,14 +297,34 @@ class ContrastiveTrainer:
         m, c = self.model, self.c
         pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
         tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
-        t_local = self.text_embeddings(tid, tmask)
+        B, T = pid.shape
+        nseg = self.num_segments
+        Bs = B // nseg
+        # The text tower and the ESM2 encodes of the segments are independent until the loss: they are enqueued on
+        # separate HIP streams so the tail of one kernel's grid (M = 2048 text GEMMs, 2.5-"round" encoder GEMMs)
+        # is filled by another stream's blocks instead of idling CUs.  Everything joins on the caller's stream.
+        main = torch.cuda.current_stream()
+        encs = []
+        if self.overlap_streams:
+            start = main.record_event()
+            with torch.cuda.stream(self._stream(0)):
+                torch.cuda.current_stream().wait_event(start)
+                t_local = self.text_embeddings(tid, tmask)
+                t_local.record_stream(main)
+                ev_text = torch.cuda.current_stream().record_event()
+            for s in range(nseg):
+                with torch.cuda.stream(self._stream(1 + s % 2)):
+                    torch.cuda.current_stream().wait_event(start)
+                    enc = m.esm_encoder.encode(pid[s * Bs:(s + 1) * Bs], pmask[s * Bs:(s + 1) * Bs])
+                    enc.record_stream(main)
+                    encs.append((enc, torch.cuda.current_stream().record_event()))
+            main.wait_event(ev_text)
+        else:
+            t_local = self.text_embeddings(tid, tmask)
         if self.global_negatives:
             t_all, offset = _gather_text(t_local, self.group)
         else:
             t_all, offset = t_local, 0
-        B, T = pid.shape
-        nseg = self.num_segments
-        Bs = B // nseg
         p_drop = float(m.adapter.dropout.p) if self.train_mode else 0.0
         wts = _lib.AdapterWeightsC(fc1_w=self.w1.data_ptr(), fc1_b=self.p[1].data_ptr(), fc2_w=self.w2.data_ptr(),
                                    fc2_b=self.p[3].data_ptr())
@@ -305,7 +332,11 @@ class ContrastiveTrainer:
         for s in range(nseg):
             sl = slice(s * Bs, (s + 1) * Bs)
             ids_s, mask_s = pid[sl], pmask[sl]
-            enc = m.esm_encoder.encode(ids_s, mask_s)                                  # [Bs, T, Hp]
+            if encs:
+                enc, ev = encs[s]
+                main.wait_event(ev)
+            else:
+                enc = m.esm_encoder.encode(ids_s, mask_s)                              # [Bs, T, Hp]
             Hp, M = enc.shape[2], Bs * T
             b = self._buffers(Bs, T)
             seed = m.adapter._next_seed() if p_drop > 0 else 0

@@ -197,7 +197,7 @@ class EsmEncoder(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         nbytes = call("p2t_esm2_workspace_bytes", C.byref(e["cfg"]), B, T)
-        ws = self._ws.get((B, T), nbytes, dev)
+        ws = self._ws.get((B, T, torch.cuda.current_stream().cuda_stream), nbytes, dev)     # one workspace per stream
         out = torch.empty((B, T, e["Hp"]), dtype=self.dtype, device=dev)
         call("p2t_esm2_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, ptr(out), e["Hp"],
              ptr(ws), ws.numel(), stream())
@@ -447,7 +447,7 @@ class LlamaTextModel(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         nbytes = call("p2t_llama_workspace_bytes", C.byref(e["cfg"]), B, T)
-        ws = self._ws.get((B, T), nbytes, dev)
+        ws = self._ws.get((B, T, torch.cuda.current_stream().cuda_stream), nbytes, dev)
         out = torch.empty((B, T, self.spec.hidden_size), dtype=torch.float32, device=dev)
         call("p2t_llama_hidden_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, int(k), ptr(out),
              ptr(ws), ws.numel(), stream())

@@ -92,7 +92,7 @@ def test_gemm_fp32(ops, epi, shape):
 
 
 @pytest.mark.parametrize("epi", [EPI_STORE, EPI_GELU, EPI_RESID, EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD])
-@pytest.mark.parametrize("shape", [(300, 320, 320), (1000, 96, 64), (4096, 4096, 128), (2048, 1184, 192)])
+@pytest.mark.parametrize("shape", [(300, 320, 320), (1000, 96, 64), (4096, 4096, 128), (2048, 1184, 192), (16500, 2560, 128)])
 def test_gemm_mfma_bf16(ops, epi, shape):
     M, N, K = shape
     if epi == EPI_SWIGLU and N % 64:

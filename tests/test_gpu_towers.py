@@ -211,3 +211,89 @@ def test_argument_errors():
         model.llama_decoder.model(input_ids=ids, attention_mask=torch.ones_like(ids), output_hidden_states=True).hidden_states[5]
     with pytest.raises(ValueError):
         P.readout_embeddings(torch.zeros((2, 8, 64), device=dev()), None, "max")
+
+
+def test_state_dict_interop_and_engine_refresh(golden):
+    """Reference-style checkpoints: HF-named state dicts (numpy -> torch) loaded with load_state_dict produce the
+    golden outputs; loading new weights invalidates the packed engine; adapter checkpoints keep the upstream keys
+    (fc1/fc2/ln1/ln2 . weight/bias, scripts/train_contrast.py:679-685)."""
+    import p2t_hip as P
+    from p2t_hip import specs
+    g = golden("tiny")
+    meta = g["meta"]
+    esm, llama, ad, pid, pmask, tid, tmask = case_setup(meta)
+    model = build_model(esm, llama, ad, torch.float32, seed=99).eval()          # wrong weights first
+    b = _batch(pid, pmask, tid, tmask)
+    with torch.no_grad():
+        wrong = to_np(model(protein_input_ids=b["protein_input_ids"], protein_attention_mask=b["protein_attention_mask"],
+                            return_adapter_outputs=True)[0])
+    assert rel(wrong, g["adapter_out"]) > 0.1
+    sd = {}
+    for tens in (specs.esm_tensors(esm, "esm_encoder."), specs.adapter_tensors(ad, "adapter."),
+                 specs.llama_tensors(llama, "llama_decoder.")):
+        sd.update({k: torch.from_numpy(v) for k, v in specs.materialize(tens, meta["seed_w"]).items()})
+    # legacy ESM checkpoints carry inv_freq per layer (HF remaps it, modeling_esm.py:654-674)
+    d = esm.head_dim
+    sd["esm_encoder.encoder.layer.0.attention.self.rotary_embeddings.inv_freq"] = 1.0 / (10000.0 ** (torch.arange(0, d, 2).float() / d))
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all("contact_head" in k or "inv_freq" in k for k in res.missing_keys), res.missing_keys
+    with torch.no_grad():
+        ad_out, _ = model(protein_input_ids=b["protein_input_ids"], protein_attention_mask=b["protein_attention_mask"],
+                          return_adapter_outputs=True)
+        t = P.l2_normalize(P.get_description_embeddings(model, b["description_input_ids"], b["description_attention_mask"], meta["layers"][-1]))
+    assert rel(to_np(ad_out), g["adapter_out"]) < F32_TOL
+    assert rel(to_np(t), g[f"text_norm_mix_L{meta['layers'][-1]}"]) < F32_TOL
+    keys = set(model.adapter.state_dict().keys())
+    assert keys == {f"{m}.{p}" for m in ("fc1", "fc2", "ln1", "ln2") for p in ("weight", "bias")}
+    assert "esm_encoder.encoder.layer.1.attention.self.query.weight" in model.state_dict()
+    assert "llama_decoder.model.layers.0.mlp.gate_proj.weight" in model.state_dict() and "llama_decoder.lm_head.weight" in model.state_dict()
+
+
+def test_dropout_mask_is_consistent_between_forward_and_backward():
+    """Train mode (p = 0.3): the backward kernels regenerate the forward's hash-based dropout masks.  Checked by a
+    directional finite difference of the loss in fp32 with a fixed seed."""
+    import p2t_hip as P
+    from p2t_hip import specs, synth
+    esm = specs.EsmSpec(num_hidden_layers=1, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+    llama = specs.LlamaSpec(num_hidden_layers=1, hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                            num_key_value_heads=2, vocab_size=256)
+    ad = specs.AdapterSpec(64, 96, 64, 0.3)
+    pid, pmask = synth.protein_batch(3, 4, 20, [20, 14, 9, 6])
+    tid, tmask = synth.text_batch(3, 4, 10, 250, [10, 7, 4, 3], 255, 254)
+    b = _batch(pid, pmask, tid, tmask)
+    model = build_model(esm, llama, ad, torch.float32, 1)
+    model.train()
+    model.adapter.requires_grad_(True)
+
+    def loss_at(delta=None, eps=0.0):
+        if delta is not None:
+            with torch.no_grad():
+                model.adapter.fc1.weight.add_(delta, alpha=eps)
+        model.adapter.manual_seed(7)
+        out = P.teacher_forcing_forward_pass(0, model, b, 1, output_llm_layer=1)
+        if delta is not None:
+            with torch.no_grad():
+                model.adapter.fc1.weight.add_(delta, alpha=-eps)
+        return out
+
+    loss = loss_at()
+    loss.backward()
+    gw = model.adapter.fc1.weight.grad.clone()
+    assert float(gw.abs().max()) > 0
+    ones = torch.ones((40, 96), dtype=torch.float32, device=dev())
+    model.adapter.eval()
+    with torch.no_grad():
+        assert rel(to_np(model.adapter.forward_padded(torch.ones((40, 64), device=dev())).norm(dim=-1)), to_np(ones[:, 0])) < 1e-5
+    model.adapter.train()
+    direction = torch.from_numpy(synth.uniform_f32(5, "fd.dir", tuple(gw.shape), 1.0)).to(dev())
+    eps = 1e-3
+    with torch.no_grad():
+        fd = (float(loss_at(direction, eps)) - float(loss_at(direction, -eps))) / (2 * eps)
+    an = float((gw * direction).sum())
+    assert abs(fd - an) < 2e-2 * max(abs(an), 1e-3), (fd, an)
+    # and a different seed changes the mask
+    model.adapter.manual_seed(8)
+    with torch.no_grad():
+        other = float(P.teacher_forcing_forward_pass(0, model, b, 1, output_llm_layer=1))
+    assert abs(other - float(loss)) > 1e-6
