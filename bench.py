@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--segments", type=int, default=1, help="contrastive_num_segments")
     ap.add_argument("--eval-mode", action="store_true", help="no adapter dropout (default: train mode, p=0.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-steps", type=int, default=3,
+                    help="timed steps whose MFMA launches are bracketed by HIP events for the roofline block "
+                         "(default: the last 3 of the timed steps -- the event records cost ~1.5 % of the step when on every launch; "
+                         "-1 = all, 0 = none)")
     ap.add_argument("--overlap", action="store_true",
                     help="text tower and encoder segments on separate HIP streams (+1-3 %% throughput; per-kernel event times "
                          "then include co-running kernels, so the roofline block is only meaningful without it)")
@@ -160,9 +164,11 @@ def main():
     for _ in range(args.warmup):
         trainer.step(batch)
     barrier()
-    _lib.call("p2t_prof_enable", 1)
+    ev_steps = args.steps if args.event_steps < 0 else min(args.event_steps, args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - ev_steps:
+            _lib.call("p2t_prof_enable", 1)
         loss = trainer.step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -187,7 +193,7 @@ def main():
         He, Le = esm.hidden_size, esm.num_hidden_layers
         attn_flops = Le * 4 * Tp * Tp * He + min(16, llama.num_hidden_layers) * 2 * (Tt + 1) * Tt * llama.hidden_size
         gemm_flops_step = (f["total"] - attn_flops) * B
-        launches_step = cnt[0] / args.steps
+        launches_step = cnt[0] / max(ev_steps, 1)
         avg_ms = ms[0] / max(cnt[0], 1)
         achieved = (gemm_flops_step / max(launches_step, 1)) / (avg_ms * 1e-3) / 1e12 if cnt[0] else 0.0
         out = {
@@ -205,7 +211,8 @@ def main():
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(args.config, B),
                          "launches_per_step": round(launches_step, 1), "avg_launch_ms": round(avg_ms, 4),
-                         "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attention_ms_per_step": round(ms[1] / args.steps, 3),
+                         "gemm_ms_per_step": round(ms[0] / max(ev_steps, 1), 3), "attention_ms_per_step": round(ms[1] / max(ev_steps, 1), 3),
+                         "event_steps": ev_steps,
                          "attention_tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:

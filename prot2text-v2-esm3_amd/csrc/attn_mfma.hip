@@ -15,6 +15,8 @@
 // which is conflict-free both for the 32-row ds_read_b128 fragment pattern (K) and for the 4-row x 64-byte
 // transpose-read pattern (V).
 // Softmax in fp32 with exp2 (log2(e) folded into the scale); P is rounded to bf16 for the PV MFMA.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -126,12 +128,15 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
         for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    if (n_it > 0) stage(0, 0);
-    for (int it = 0; it < n_it; ++it) {
+    // One 64-key step on LDS buffer BUF (a compile-time constant: every ds_read address is then a per-lane VGPR
+    // plus an immediate, no per-read address arithmetic on the VALU, which is the busier pipe in this kernel).
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto bufc, int it) {
+        constexpr int BUF = decltype(bufc)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (it + 1 < n_it) stage((it + 1) & 1, it + 1);
-        const char* sb = smem + (it & 1) * STAGE;
+        if (it + 1 < n_it) stage(BUF ^ 1, it + 1);
+        const char* sb = smem + BUF * STAGE;
         const int kb = it * 64;
 
         // S^T tiles: rows = keys (permuted), cols = queries
@@ -139,11 +144,9 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-#pragma unroll
             for (int kk = 0; kk < DK; ++kk) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off[t][kk]);
-                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[t], 0, 0, 0);
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : st[t], 0, 0, 0);
             }
         }
         // Masking only where a key of this 64-key step can be hidden from a query of this wave (tail of the
@@ -152,15 +155,25 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
         // Register r of tile t is key kb + 32t + 16(r>>3) + 8hh + (r&7).
         const bool need_mask = (kb + 64 > end) || (causal && kb + 63 > q0) || !prefix;
         if (need_mask) {
+            // visible keys of this lane's query: key < lim, lim = min(end, causal ? query + 1 : end); per register
+            // the key is kb + 8 hh + (32 t + 16 (r >> 3) + (r & 7)), so one compare against a per-lane limit
+            const int lim = (causal ? min(end, query + 1) : end) - kb - 8 * hh;
+            if (prefix) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb + 32 * t + 16 * (r >> 3) + 8 * hh + (r & 7);
-                    bool ok = key < end && (!causal || key <= query);
-                    if (!prefix) ok = ok && key < seq && key_mask[(int64_t)b * seq + (key < seq ? key : 0)];
-                    st[t][r] = ok ? st[t][r] : -INFINITY;
-                }
+                    for (int r = 0; r < 16; ++r) st[t][r] = (32 * t + 16 * (r >> 3) + (r & 7)) < lim ? st[t][r] : -INFINITY;
+            } else {
+                const uint8_t* mrow = key_mask + (int64_t)b * seq + kb + 8 * hh;    // arbitrary mask: byte per key
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = 32 * t + 16 * (r >> 3) + (r & 7);
+                        const bool ok = off < lim && mrow[min(off, seq - 1 - kb - 8 * hh)] != 0;
+                        st[t][r] = ok ? st[t][r] : -INFINITY;
+                    }
+            }
         }
         float mloc = -INFINITY;
 #pragma unroll
@@ -203,6 +216,11 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
                 ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, ot[dt], 0, 0, 0);
             }
         }
+    };
+    if (n_it > 0) stage(0, 0);
+    for (int it = 0; it < n_it; it += 2) {
+        step(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < n_it) step(std::integral_constant<int, 1>{}, it + 1);
     }
 
     // ---- epilogue: O^T rows = channels (r&3) + 8(r>>2) + 4hh, col = query ----

@@ -290,15 +290,28 @@ __global__ void __launch_bounds__(512) lab_kernel3(const bf16_t* __restrict__ A,
         if (!(ABL & 8)) __builtin_amdgcn_sched_barrier(0);
         mfma_all(xc, wc);
         if ((ABL & 8) && FULL) {      // interleave: MFMAs start right after the barrier, one LDS read / DMA issue per 2 MFMAs
+            if (ABL & 16) {           // DMA issue first (its latency is the long one), then the fragment reads
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                for (int q = 0; q < 12; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -399,6 +412,8 @@ extern "C" float lab_gemm(int var, int abl, const void* A, int64_t lda, const vo
     if (var == 3 && abl == 4) return run3<4>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
     if (var == 3 && abl == 8) return run3<8>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
     if (var == 3 && abl == 9) return run3<9>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 24) return run3<24>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
+    if (var == 3 && abl == 10) return run3<10>(A, lda, W, ldw, bias, C, ldc, M, N, K, iters, s);
 #undef CASE
     return -2.f;
 }
