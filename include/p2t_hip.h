@@ -78,10 +78,14 @@ int p2t_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, v
  * (v_mfma_f32_16x16x32_bf16, 256x256x64 LDS tiles); otherwise the fp32-FMA kernel.  bias: f32 [N] or NULL.
  * out: `out_dtype` [M, ldc]; columns N..min(ldc, N rounded up to 64)-1 are written as zeros (they are the zero
  * K-padding of the next GEMM).  z (GELU only, may be NULL): pre-activation, out_dtype, same stride.  EPI_RESID: out is f32 and accumulated in place.  EPI_SWIGLU: N is the
- * interleaved gate/up row count (a multiple of 64), out has N/2 columns.  use_mfma: -1 auto, 0 force FMA kernel, 1 require MFMA. */
+ * interleaved gate/up row count (a multiple of 64), out has N/2 columns.  use_mfma: -1 auto, 0 force FMA kernel, 1 require MFMA.
+ * fix_ws (optional, p2t_gemm_fix_workspace_bytes() bytes): lets the MFMA kernel run the tiles of a last partial
+ * "round" of the 256 CUs as two concurrent K halves (split-K fix-up).  Its first 2048 bytes must have been zeroed
+ * (once) before a sequence of calls that pass strictly increasing fix_epoch values >= 1. */
 int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                 void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
-                int use_mfma, p2t_stream stream);
+                int use_mfma, void* fix_ws, size_t fix_ws_bytes, unsigned fix_epoch, p2t_stream stream);
+size_t p2t_gemm_fix_workspace_bytes(void);
 
 /* torch.nn.LayerNorm over the last dim: x f32 [rows, ld_x] -> y `out_dtype` [rows, ld_y]; pad zeroed. */
 int p2t_layernorm(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* y, int64_t ld_y,

@@ -77,7 +77,8 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     }
     if (can_mfma && a.use_mfma != 0) {
         const int pi = prof_begin(s, 0, 2.0 * (double)a.M * (double)a.N * (double)a.K);
-        const int rc = launch_gemm_mfma(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, out_dtype, a.epilogue, ep, a.tile, s);
+        const int rc = launch_gemm_mfma(a.A, a.lda, a.W, a.ldw, a.M, (int)a.N, (int)a.K, n_cover, out_dtype, a.epilogue, ep, a.tile, a.fix_ws,
+                                        a.fix_bytes, a.fix_epoch, s);
         prof_end(s, pi);
         return rc;
     }
@@ -125,10 +126,13 @@ extern "C" int p2t_prof_collect(double* ms, int64_t* launches, double* flops, in
 
 extern "C" int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                            void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
-                           int use_mfma, p2t_stream stream) {
+                           int use_mfma, void* fix_ws, size_t fix_ws_bytes, unsigned fix_epoch, p2t_stream stream) {
     GemmArgs a{A, lda, W, ldw, bias, out, ldc, z, M, N, K, dtype, out_dtype, epilogue, accumulate, use_mfma, -1, 0.f, 0, 0};
+    a.fix_ws = fix_ws; a.fix_bytes = fix_ws_bytes; a.fix_epoch = fix_epoch;
     return gemm_nt(a, (hipStream_t)stream);
 }
+
+extern "C" size_t p2t_gemm_fix_workspace_bytes(void) { return gemm_fix_workspace_bytes(); }
 
 extern "C" int p2t_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
                                 uint8_t* key_mask, int32_t* kv_info, float* emb_scale, p2t_stream stream) {

@@ -44,11 +44,21 @@ __device__ __forceinline__ void tile_coords(int id, int n_items, int tiles_m, in
     tn = in_band / gm;
 }
 
-// One BM x 256 output tile at (m0, n0).  smem: 4 * (BM + 256) * 64 bytes.
-template <int MT, typename Epi>
+// Split-K fix-up of the tail round (see gemm_nt_mfma_tail_kernel): one fp32 accumulator slab per tail tile in the
+// register order of the block (thread t, register quad i -> float4 slab[i * 512 + t]) and one flag word per tile.
+struct SplitFix {
+    float* slab;            // [n_tail][32][512] float4 = 256 KiB per tile
+    unsigned* flag;         // [n_tail], holds the epoch of the last completed producer
+    unsigned* timeout;      // set to 1 if a consumer ever gave up waiting (never expected; bounded spin)
+    unsigned epoch;         // unique per launch within one zeroing of `flag`
+};
+enum { TILE_FULL = 0, TILE_PRODUCE = 1, TILE_CONSUME = 2 };
+
+// One BM x 256 output tile at (m0, n0) over K range [k0, k0 + 32 ns).  smem: 4 * (BM + 256) * 64 bytes.
+template <int MT, typename Epi, int MODE = TILE_FULL>
 __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
-                                          int64_t ldw, int64_t M, int N, int K, int64_t m0, int n0, int n_cover,
-                                          const EpiParams& ep) {
+                                          int64_t ldw, int64_t M, int N, int k0, int ns, int64_t m0, int n0, int n_cover,
+                                          const EpiParams& ep, const SplitFix* fix = nullptr, int fix_tile = 0) {
     constexpr int WN = 4, NT = 4, BM = 2 * MT * 16, BN = 256;
     constexpr int AI = BM / 128;                            // A staging instructions per wave per stage (1 KiB each)
     constexpr int SLOT = (BM + BN) * 64;                    // bytes per 32-deep stage
@@ -65,7 +75,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
     for (int t = 0; t < AI; ++t) {
         int64_t am = m0 + (w * AI + t) * 16 + (lane >> 2);
         am = am < M ? am : M - 1;
-        a_src[t] = A + am * lda + schunk * 8;
+        a_src[t] = A + am * lda + k0 + schunk * 8;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -73,7 +83,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
         const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);     // permuted weight row
         int wr = n0 + (R & ~63) + nl;
         wr = wr < N ? wr : N - 1;
-        w_src[t] = W + (int64_t)wr * ldw + schunk * 8;
+        w_src[t] = W + (int64_t)wr * ldw + k0 + schunk * 8;
     }
     auto stage = [&](int s) {
         char* base = smem + (s & 3) * SLOT;
@@ -98,7 +108,6 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int ns = K >> 5;
     auto load_frags = [&](int s, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
         const char* sb = smem + (s & 3) * SLOT;
 #pragma unroll
@@ -165,6 +174,50 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
         step(std::false_type{}, s + 1, xb, wb, xa, wa);
     }
 
+    if constexpr (MODE == TILE_PRODUCE) {
+        // second K half of a tail tile: publish the raw accumulators (plain 16-B stores, coalesced), then every wave
+        // drains its stores, the block barriers, and one lane releases at agent scope and raises the tile's flag
+        // (cdna_hip_programming.md Guideline 16, counter form).  This block never waits: it cannot deadlock.
+        float4* slab = reinterpret_cast<float4*>(fix->slab) + (int64_t)fix_tile * (MT * NT * 512);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                slab[(i * MT + j) * 512 + threadIdx.x] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(fix->flag + fix_tile, fix->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if constexpr (MODE == TILE_CONSUME) {
+        // first K half: wait for the partner (dispatched earlier, so it is running or done), acquire, add its slab
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(fix->flag + fix_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fix->epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) {                  // ~ seconds: give up loudly instead of hanging the GPU
+                    __hip_atomic_store(fix->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const float4* slab = reinterpret_cast<const float4*>(fix->slab) + (int64_t)fix_tile * (MT * NT * 512);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const float4 p = slab[(i * MT + j) * 512 + threadIdx.x];
+                acc[i][j][0] += p.x; acc[i][j][1] += p.y; acc[i][j][2] += p.z; acc[i][j][3] += p.w;
+            }
+    }
+
     // ---- epilogue: lane owns row m, columns nb .. nb+7 (n-tiles 0,1) and nb+32 .. nb+39 (n-tiles 2,3) ----
     const int nb = n0 + wn * 64 + kg * 8;
     if (nb >= n_cover) return;
@@ -193,7 +246,34 @@ __global__ void __launch_bounds__(512)
     __shared__ __attribute__((aligned(16))) char smem[4 * (BM + 256) * 64];
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
-    gemm_tile<MT, Epi>(smem, A, lda, W, ldw, M, N, K, (int64_t)tm * BM, tn * 256, n_cover, ep);
+    gemm_tile<MT, Epi>(smem, A, lda, W, ldw, M, N, 0, K >> 5, (int64_t)tm * BM, tn * 256, n_cover, ep);
+}
+
+// Wave-quantisation fix for grids that are not a whole number of "rounds" of the 256 CUs (o-proj / FFN-down of the
+// encoder: 640 tiles = 2.5 rounds): the first n_full blocks take whole tiles; each of the n_tail leftover tiles is
+// split in two K halves run by two CUs at the same time -- a producer block (second half; dispatched FIRST, never
+// waits) and a consumer block (first half, then adds the producer's slab and runs the epilogue).  The last partial
+// round then costs about half a round plus the 256 KiB slab hand-off instead of a full round.
+template <typename Epi>
+__global__ void __launch_bounds__(512)
+    gemm_nt_mfma_tail_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M,
+                             int N, int K, int tiles_m, int tiles_n, int n_full, int n_tail, int n_cover, EpiParams ep,
+                             SplitFix fix) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 512 * 64];
+    const int bid = blockIdx.x, ns = K >> 5, ns0 = (ns >> 1) & ~1;     // consumer: stages [0, ns0), producer: [ns0, ns)
+    int tm, tn;
+    if (bid < n_full) {
+        tile_coords(bid, n_full + n_tail, tiles_m, tiles_n, tm, tn);   // tail tiles = the last ids of the same order
+        gemm_tile<8, Epi>(smem, A, lda, W, ldw, M, N, 0, ns, (int64_t)tm * 256, tn * 256, n_cover, ep);
+    } else if (bid < n_full + n_tail) {
+        const int t = bid - n_full;
+        tile_coords(n_full + t, n_full + n_tail, tiles_m, tiles_n, tm, tn);
+        gemm_tile<8, Epi, TILE_PRODUCE>(smem, A, lda, W, ldw, M, N, ns0 * 32, ns - ns0, (int64_t)tm * 256, tn * 256, n_cover, ep, &fix, t);
+    } else {
+        const int t = bid - n_full - n_tail;
+        tile_coords(n_full + t, n_full + n_tail, tiles_m, tiles_n, tm, tn);
+        gemm_tile<8, Epi, TILE_CONSUME>(smem, A, lda, W, ldw, M, N, 0, ns0, (int64_t)tm * 256, tn * 256, n_cover, ep, &fix, t);
+    }
 }
 
 template <int MT, typename Epi>
@@ -213,45 +293,70 @@ static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, in
 constexpr double kSmallTileCost = 0.625;
 constexpr int kCUs = 256;
 
+// Layout of the split-K fix-up workspace: [0, 1024) flag words, [1024, 1088) timeout word, [2048, ...) slabs.
+constexpr size_t kFixHeader = 2048, kFixSlab = 256 * 256 * sizeof(float);
+size_t gemm_fix_workspace_bytes() { return kFixHeader + 128 * kFixSlab; }
+size_t gemm_fix_header_bytes() { return kFixHeader; }
+
 template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
-                        const EpiParams& ep, int tile, hipStream_t s) {
+                        const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes, unsigned fix_epoch, hipStream_t s) {
     static const int env_tile = [] {                       // experiments only: P2T_GEMM_TILE=128|256 forces a tile height
-        const char* e = getenv("P2T_GEMM_TILE");
+        const char* e = getenv("P2T_GEMM_TILE");           //                   P2T_GEMM_TILE=1 disables the split-K tail
         return e ? atoi(e) : 0;
     }();
     if (tile == 0) tile = env_tile;
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);
     const double cost128 = (double)ceil_div(tm128 * tn, kCUs) * kSmallTileCost * 1.08;
-    if (tile == 256 || (tile != 128 && cost256 <= cost128))
+    if (tile == 256 || (tile != 128 && cost256 <= cost128)) {
+        // split-K tail: leftover tiles of the last partial round (at most half a round) run as two K halves each
+        const int64_t total = tm256 * tn, n_full = (total / kCUs) * kCUs, n_tail = total - n_full;
+        // measured (profiles/r01_microbench_v3.log): pays for long K (FFN-down +8 %) or many full rounds (QKV +5 %);
+        // with K = 2560 and only two full rounds (o-proj) the slab hand-off costs more than the half round it saves
+        const int ns = K >> 5;
+        const bool worth = ns >= 128 || (ns >= 64 && n_full >= 4 * kCUs);
+        if (tile == 0 && fix_ws && n_full > 0 && n_tail > 0 && n_tail <= 128 && worth &&
+            fix_bytes >= kFixHeader + (size_t)n_tail * kFixSlab) {
+            SplitFix fix;
+            fix.flag = (unsigned*)fix_ws;
+            fix.timeout = (unsigned*)((char*)fix_ws + 1024);
+            fix.slab = (float*)((char*)fix_ws + kFixHeader);
+            fix.epoch = fix_epoch;
+            gemm_nt_mfma_tail_kernel<Epi><<<dim3((unsigned)(n_full + 2 * n_tail)), 512, 0, s>>>(
+                (const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)tm256, (int)tn, (int)n_full, (int)n_tail, n_cover, ep, fix);
+            P2T_LAUNCH_CHECK();
+            return P2T_OK;
+        }
         return launch_cfg<8, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+    }
     return launch_cfg<4, Epi>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
 }
 
 int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
-                     int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s) {
+                     int out_dtype, int epilogue, const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes,
+                     unsigned fix_epoch, hipStream_t s) {
     const bool ob = out_dtype == P2T_BF16;
     switch (epilogue) {
         case P2T_EPI_STORE:
-            return ob ? launch_shape<EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
-                      : launch_shape<EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return ob ? launch_shape<EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
+                      : launch_shape<EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_GELU:
-            return ob ? launch_shape<EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
-                      : launch_shape<EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return ob ? launch_shape<EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
+                      : launch_shape<EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_RESID:
-            return launch_shape<EpiResid>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return launch_shape<EpiResid>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_SWIGLU:
-            return ob ? launch_shape<EpiSwiglu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
-                      : launch_shape<EpiSwiglu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return ob ? launch_shape<EpiSwiglu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
+                      : launch_shape<EpiSwiglu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_STORE_F32:
-            return launch_shape<EpiF32>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return launch_shape<EpiF32>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_GELU_BWD:
-            return ob ? launch_shape<EpiGeluBwd<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
-                      : launch_shape<EpiGeluBwd<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return ob ? launch_shape<EpiGeluBwd<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
+                      : launch_shape<EpiGeluBwd<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_QKV_ROPE:
-            return ob ? launch_shape<EpiQkvRope<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s)
-                      : launch_shape<EpiQkvRope<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, s);
+            return ob ? launch_shape<EpiQkvRope<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
+                      : launch_shape<EpiQkvRope<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
     }
     set_error("gemm: unknown epilogue %d", epilogue);
     return P2T_ERR_ARG;

@@ -31,7 +31,10 @@ int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void
 int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int dtype,
                        int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s);
 int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
-                     int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s);
+                     int out_dtype, int epilogue, const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes,
+                     unsigned fix_epoch, hipStream_t s);
+size_t gemm_fix_workspace_bytes();       // split-K tail fix-up workspace (flags + slabs); header must be zeroed once per
+size_t gemm_fix_header_bytes();          // sequence of launches that use distinct epochs
 // full dispatcher behind p2t_gemm_nt (gemm.hip)
 struct GemmArgs {
     const void* A; int64_t lda; const void* W; int64_t ldw; const float* bias; void* out; int64_t ldc; void* z;
@@ -42,6 +45,8 @@ struct GemmArgs {
     // P2T_EPI_QKV_ROPE only (head_dim 64): rotary table [T, 64], outputs [B, heads, T, 64]
     const float* cs = nullptr; void* q = nullptr; void* k = nullptr; void* v = nullptr;
     int seq = 0, nh = 0, nkv = 0; float q_scale = 1.f;
+    // optional split-K tail fix-up (MFMA kernel, 256-row tiles): workspace + an epoch unique since its header was zeroed
+    void* fix_ws = nullptr; size_t fix_bytes = 0; unsigned fix_epoch = 0;
 };
 int gemm_nt(const GemmArgs& a, hipStream_t s);
 

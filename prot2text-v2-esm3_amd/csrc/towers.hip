@@ -14,7 +14,7 @@ namespace {
 
 struct EsmBuffers {
     uint8_t* key_mask; int32_t* kv_info; float* emb_scale; float* inv_freq; float* cs;
-    float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* ffn;
+    float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* ffn; void* fix;
 };
 
 size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b) {
@@ -37,6 +37,7 @@ size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b
     t.v = a.take(e * (size_t)B * nh * T * dp);
     t.ao = a.take(e * (size_t)M * Hp);
     t.ffn = a.take(e * (size_t)M * Fp);
+    t.fix = a.take(gemm_fix_workspace_bytes());
     if (b) *b = t;
     return a.off + 256;
 }
@@ -110,6 +111,9 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
     }
     P2T_TRY(launch_rope_table(inv_freq, T, d / 2, b.cs, s));
     const float q_scale = 1.0f / sqrtf((float)d);           // ESM scales q before rotary; SDPA scale is 1.0
+    P2T_CHECK_HIP(hipMemsetAsync(b.fix, 0, gemm_fix_header_bytes(), s));      // split-K tail flags; epochs below are unique
+    unsigned epoch = 0;
+    auto with_fix = [&](GemmArgs& g) { g.fix_ws = b.fix; g.fix_bytes = gemm_fix_workspace_bytes(); g.fix_epoch = ++epoch; };
     for (int l = 0; l < c->n_layers; ++l) {
         const p2t_esm2_layer& L = w->layers[l];
         P2T_TRY(launch_layernorm(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
@@ -117,6 +121,7 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
             // QKV projection with bias + q-scale + rotary + head split fused into the GEMM epilogue
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, L.qkv_b, nullptr, 0, nullptr, M, 3 * H, Hp, dt, dt, P2T_EPI_QKV_ROPE, 0, -1, -1, 0.f, 0, 0};
             g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nh; g1.q_scale = q_scale;
+            with_fix(g1);
             P2T_TRY(gemm_nt(g1, s));
         } else {
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, L.qkv_b, b.qkv, 3 * H, nullptr, M, 3 * H, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)(3 * H), 0.f, 0, 0};
@@ -125,11 +130,14 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
         }
         P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, s));
         GemmArgs g2{b.ao, Hp, L.o_w, Hp, L.o_b, b.x, H, nullptr, M, H, Hp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        with_fix(g2);
         P2T_TRY(gemm_nt(g2, s));
         P2T_TRY(launch_layernorm(b.x, H, L.ln2_w, L.ln2_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
         GemmArgs g3{b.h, Hp, L.fc1_w, Hp, L.fc1_b, b.ffn, Fp, nullptr, M, F, Hp, dt, dt, P2T_EPI_GELU, 0, -1, -1, 0.f, 0, 0};
+        with_fix(g3);
         P2T_TRY(gemm_nt(g3, s));
         GemmArgs g4{b.ffn, Fp, L.fc2_w, Fp, L.fc2_b, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        with_fix(g4);
         P2T_TRY(gemm_nt(g4, s));
     }
     return launch_layernorm(b.x, H, w->final_ln_w, w->final_ln_b, c->layer_norm_eps, out, ld_out, M, H, dt, s);

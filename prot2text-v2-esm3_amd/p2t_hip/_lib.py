@@ -88,7 +88,8 @@ SIGNATURES = {
     "p2t_cast": (i32, [vp, i32, vp, i32, i64, vp]),
     "p2t_scale_by_device_scalar": (i32, [vp, i64, vp, vp]),
     "p2t_transpose": (i32, [vp, i64, i64, i64, vp, i64, i32, vp]),
-    "p2t_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "p2t_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32, vp, sz, C.c_uint, vp]),
+    "p2t_gemm_fix_workspace_bytes": (sz, []),
     "p2t_layernorm": (i32, [vp, i64, vp, vp, f32, vp, i64, i64, i64, i32, vp]),
     "p2t_rmsnorm": (i32, [vp, i64, vp, f32, vp, i64, i64, i64, i32, vp]),
     "p2t_mask_prepare": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
@@ -126,7 +127,7 @@ for _i, _s in enumerate(_STRUCTS):
     if lib.p2t_struct_size(_i) != C.sizeof(_s):
         raise ImportError(f"ABI mismatch: {_s.__name__} is {C.sizeof(_s)} bytes here, {lib.p2t_struct_size(_i)} in the library")
 
-_NO_RC = {"p2t_version", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes",
+_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes",
           "p2t_adapter_backward_workspace_bytes"}
 
 

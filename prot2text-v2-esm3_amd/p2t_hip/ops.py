@@ -75,7 +75,7 @@ def transpose(src: torch.Tensor, ld_dst: int | None = None) -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *, n: int | None = None,
             k: int | None = None, epilogue: int = _lib.EPI_STORE, out: torch.Tensor | None = None,
             out_dtype: torch.dtype | None = None, z: torch.Tensor | None = None, accumulate: bool = False,
-            use_mfma: int = -1) -> torch.Tensor:
+            use_mfma: int = -1, fix_ws: torch.Tensor | None = None, fix_epoch: int = 0) -> torch.Tensor:
     """out = epilogue(a[:, :k] @ w[:n, :k].T).  a: [M, lda], w: [>=n, ldw] (row strides = storage width)."""
     _chk(a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1, "gemm_nt: 2-D row-major operands")
     _chk(a.dtype == w.dtype, "gemm_nt: operand dtypes differ")
@@ -88,8 +88,14 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
         ldc = n_out if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else round_up(n_out, 64)
         out = torch.empty((M, ldc), dtype=od, device=a.device)
     call("p2t_gemm_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), ptr(z), M, n, k,
-         dt_of(a), dt_of(out), epilogue, int(accumulate), use_mfma, stream())
+         dt_of(a), dt_of(out), epilogue, int(accumulate), use_mfma, ptr(fix_ws), fix_ws.numel() if fix_ws is not None else 0,
+         int(fix_epoch), stream())
     return out
+
+
+def gemm_fix_workspace(device) -> torch.Tensor:
+    """Zeroed split-K fix-up workspace for gemm_nt(fix_ws=..., fix_epoch=1, 2, ...)."""
+    return torch.zeros((call("p2t_gemm_fix_workspace_bytes"),), dtype=torch.uint8, device=device)
 
 
 def layernorm(x, w, b, eps, out_dtype=torch.float32, ld_out=None):

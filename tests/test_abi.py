@@ -38,7 +38,7 @@ def test_struct_sizes_match():
 def test_argument_errors_without_gpu():
     from p2t_hip import _lib
     with pytest.raises(ValueError, match="null"):
-        _lib.call("p2t_gemm_nt", None, 64, None, 64, None, None, 64, None, 8, 16, 64, 0, 0, 0, 0, -1, None)
+        _lib.call("p2t_gemm_nt", None, 64, None, 64, None, None, 64, None, 8, 16, 64, 0, 0, 0, 0, -1, None, 0, 0, None)
     with pytest.raises(ValueError):
         _lib.call("p2t_layernorm", None, 4, None, None, 1e-5, None, 4, 1, 4, 0, None)
     cfg = _lib.EsmConfigC(n_layers=1, hidden=64, ffn=128, heads=4, head_dim=16, vocab=33, dtype=0)

@@ -299,3 +299,25 @@ def test_clip_adamw(ops, max_norm):
             np.testing.assert_allclose(to_np(t), P[n], rtol=2e-6, atol=1e-7)
     assert np.array_equal(to_np(sh1)[:, :32], bf16r(to_np(dp[0]))) and not to_np(sh1)[:, 32:].any()
     assert np.array_equal(to_np(sh2)[:, :48], bf16r(to_np(dp[2])))
+
+
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_RESID, EPI_GELU])
+def test_gemm_mfma_splitk_tail(ops, epi):
+    """640 tiles = 2.5 rounds of the 256 CUs: with a fix-up workspace the last 128 tiles run as two concurrent K
+    halves (producer slab -> consumer epilogue).  Must equal the plain kernel bit for bit in structure-independent
+    terms (same fp32 sums up to the order of the two K halves) and the oracle; repeated launches reuse the flags."""
+    M, N, K = 16384, 2560, 4096
+    a, w = bf16r(rnd(12, "s.a", (M, K), 1.0)), bf16r(rnd(12, "s.w", (N, K), 0.3))
+    bias = rnd(12, "s.b", (N,), 0.3)
+    resid = rnd(12, "s.r", (M, N), 1.0)
+    ad, wd, bd = to_dev(a, torch.bfloat16), to_dev(w, torch.bfloat16), to_dev(bias)
+    ref = _gemm_ref(a, w, bias, epi, resid, None)
+    ws = ops.gemm_fix_workspace(dev())
+    for epoch in (1, 2, 3):
+        out = to_dev(resid) if epi == EPI_RESID else None
+        got = to_np(ops.gemm_nt(ad, wd, bd, epilogue=epi, out=out, use_mfma=1, fix_ws=ws, fix_epoch=epoch))
+        assert rel(got[:, :N], ref) < (3e-6 if epi == EPI_RESID else 3e-3), epoch
+    flags = ws[:2048].view(torch.int32).cpu().numpy()
+    assert (flags[:128] == 3).all() and flags[256] == 0          # every tail tile was published; no consumer timed out
+    plain = to_np(ops.gemm_nt(ad, wd, bd, epilogue=epi, out=to_dev(resid) if epi == EPI_RESID else None, use_mfma=1))
+    assert rel(got[:, :N], plain[:, :N]) < (1e-6 if epi == EPI_RESID else 2e-3)

@@ -44,7 +44,14 @@ def bench_gemm():
         bias = None if epi == 3 else rand((N,), torch.float32, 0.1)
         out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
         ms = timeit(lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1))
-        print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
+        ws, ep = ops.gemm_fix_workspace(dev), [0]
+
+        def with_tail():
+            ep[0] += 1
+            ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1, fix_ws=ws, fix_epoch=ep[0])
+        ms2 = timeit(with_tail)
+        fl = 2.0 * M * N * K / 1e9
+        print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: {ms:8.3f} ms  {fl / ms:8.1f} TF/s | split-K tail {ms2:8.3f} ms {fl / ms2:8.1f} TF/s", flush=True)
 
 
 def bench_attn():
