@@ -76,8 +76,15 @@ template <int W> __device__ __forceinline__ void zeroW(float (&v)[W]) {
         group<W>(p, m, n + 32, v1, b1);                                                                         \
     }
 
+// kMinOps (every functor): a LOWER bound of the vector-memory instructions one apply2<8> call issues on a tile that
+// lies fully inside the output -- the persistent GEMM keeps that many more operations in flight across a tile
+// boundary (counted s_waitcnt vmcnt), so the next tile's main loop does not wait for the epilogue stores to drain.
+template <typename Tout> constexpr int kStoreOps8 = (int)(8 * sizeof(Tout) / 16);     // 16-byte stores per 8 values
+
 template <typename Tout>
 struct EpiStore {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
     template <int W>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
@@ -96,6 +103,8 @@ struct EpiStore {
 
 template <typename Tout>
 struct EpiGelu {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
     template <int W>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
@@ -121,6 +130,8 @@ struct EpiGelu {
 // backward through dropout(gelu(z)): out = acc * gelu'(z) * dropout_mask; z is READ (layout of out)
 template <typename Tout>
 struct EpiGeluBwd {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = 4 * kStoreOps8<Tout>;
     template <int W>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
@@ -143,6 +154,24 @@ struct EpiGeluBwd {
 
 // residual stream (f32) += acc + bias, in place
 struct EpiResid {
+    static constexpr bool kRmw = true;
+    static constexpr int kMinOps = 8;
+    // interior tiles only: the stream values of both column groups, fetched ahead of the adds
+    template <int W>
+    __device__ __forceinline__ static void fetch2(const EpiParams& p, int64_t m, int n, float (&r0)[W], float (&r1)[W]) {
+        const float* o = (const float*)p.out + m * p.ldc + n;
+        loadW<W>(o, r0);
+        loadW<W>(o + 32, r1);
+    }
+    template <int W>
+    __device__ __forceinline__ static void apply2_fetched(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
+                                                          const float (&b0)[W], const float (&b1)[W], float (&r0)[W], float (&r1)[W]) {
+        float* o = (float*)p.out + m * p.ldc + n;
+#pragma unroll
+        for (int j = 0; j < W; ++j) { r0[j] += v0[j] + b0[j]; r1[j] += v1[j] + b1[j]; }
+        storeW<W>(o, r0);
+        storeW<W>(o + 32, r1);
+    }
     template <int W>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         if (n >= p.N) return;
@@ -158,6 +187,8 @@ struct EpiResid {
 
 // f32 store / accumulate (gradients)
 struct EpiF32 {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = 4;
     template <int W>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         if (n >= p.N) return;
@@ -179,6 +210,8 @@ struct EpiF32 {
 // out[m, f] = silu(gate_f) * up_f with f = (n / 64) * 32 + (n % 32): gate in the first group, up in the partner.
 template <typename Tout>
 struct EpiSwiglu {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = kStoreOps8<Tout>;
     template <int W>
     __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&g)[W], const float (&u)[W],
                                                   const float (&b0)[W], const float (&b1)[W]) {
@@ -201,6 +234,8 @@ struct EpiSwiglu {
 // attention call (modeling_esm.py:362-378) and LlamaAttention.forward (modeling_llama.py:254-259) for d = 64.
 template <typename Tout>
 struct EpiQkvRope {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
     template <int W>
     __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
                                                   const float (&b0)[W], const float (&b1)[W]) {

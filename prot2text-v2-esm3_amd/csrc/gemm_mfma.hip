@@ -54,6 +54,48 @@ struct SplitFix {
 };
 enum { TILE_FULL = 0, TILE_PRODUCE = 1, TILE_CONSUME = 2 };
 
+// Epilogue of one tile: lane owns row m, columns nb .. nb+7 (n-tiles 0,1) and nb+32 .. nb+39 (n-tiles 2,3).
+// INTERIOR: the tile lies fully inside the output (no row / column checks, one basic block).  Read-modify-write
+// epilogues (Epi::kRmw) then fetch their operand for four rows at a time before the first add, so the HBM latency of
+// the residual read is paid twice per tile instead of once per row.
+template <int MT, typename Epi, bool INTERIOR = false>
+__device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[4][MT], const EpiParams& ep, int64_t M, int N, int n_cover,
+                                              int64_t m0, int n0, int wm, int wn, int fr, int kg) {
+    const int nb = n0 + wn * 64 + kg * 8;
+    if (!INTERIOR && nb >= n_cover) return;
+    float b0[8], b1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b0[e] = b1[e] = 0.f;
+    if (ep.bias) {
+        if (INTERIOR || nb < N) loadW<8>(ep.bias + nb, b0);
+        if (INTERIOR || nb + 32 < N) loadW<8>(ep.bias + nb + 32, b1);
+    }
+    if constexpr (INTERIOR && Epi::kRmw && MT % 4 == 0) {
+#pragma unroll
+        for (int jb = 0; jb < MT; jb += 4) {
+            float r0[4][8], r1[4][8];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) Epi::template fetch2<8>(ep, m0 + wm * MT * 16 + (jb + jj) * 16 + fr, nb, r0[jj], r1[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = jb + jj;
+                const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+                const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+                Epi::template apply2_fetched<8>(ep, m0 + wm * MT * 16 + j * 16 + fr, nb, v0, v1, b0, b1, r0[jj], r1[jj]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
+            if (!INTERIOR && m >= M) continue;
+            const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+            const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+            Epi::template apply2<8>(ep, m, nb, v0, v1, b0, b1);
+        }
+    }
+}
+
 // One BM x 256 output tile at (m0, n0) over K range [k0, k0 + 32 ns).  smem: 4 * (BM + 256) * 64 bytes.
 template <int MT, typename Epi, int MODE = TILE_FULL>
 __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
@@ -218,24 +260,7 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
             }
     }
 
-    // ---- epilogue: lane owns row m, columns nb .. nb+7 (n-tiles 0,1) and nb+32 .. nb+39 (n-tiles 2,3) ----
-    const int nb = n0 + wn * 64 + kg * 8;
-    if (nb >= n_cover) return;
-    float b0[8], b1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b0[e] = b1[e] = 0.f;
-    if (ep.bias) {
-        if (nb < N) loadW<8>(ep.bias + nb, b0);
-        if (nb + 32 < N) loadW<8>(ep.bias + nb + 32, b1);
-    }
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
-        if (m >= M) continue;
-        const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
-        const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-        Epi::template apply2<8>(ep, m, nb, v0, v1, b0, b1);
-    }
+    tile_epilogue<MT, Epi>(acc, ep, M, N, n_cover, m0, n0, wm, wn, fr, kg);
 }
 
 template <int MT, typename Epi>
@@ -247,6 +272,223 @@ __global__ void __launch_bounds__(512)
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
     gemm_tile<MT, Epi>(smem, A, lda, W, ldw, M, N, 0, K >> 5, (int64_t)tm * BM, tn * 256, n_cover, ep);
+}
+
+// s_waitcnt vmcnt(n) only: simm16 = vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
+constexpr int vm_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+
+// Persistent form of the 256 x 256 tile: one block per CU walks work items blockIdx.x, + gridDim.x, ... and treats the
+// K loops of consecutive tiles as ONE stream of stages -- the last three steps of a tile already issue the LDS DMA of
+// the next tile's first three stages, so no tile after the first pays the ring fill, and the epilogue's stores are
+// never drained: vmcnt completes in issue order (MI355X_MICROARCH.md, s_waitcnt), so the first two steps after an
+// epilogue wait with a count that leaves the epilogue's operations in flight (Epi::kMinOps is a lower bound of them;
+// the kernel only takes shapes without edge tiles, where every wave issues all of them).  The write burst of a round (all CUs finish together: 32 MB, ~6 us of HBM time) then overlaps the next tile's MFMAs.
+// Requirements on top of the plain kernel: M % 256 == 0, N % 256 == 0 == n_cover (no edge tiles), (K / 32) % 4 == 0,
+// K >= 384, n_items >= gridDim.x.
+template <typename Epi>
+__global__ void __launch_bounds__(512)
+    gemm_nt_mfma_persist_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M,
+                                int N, int K, int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep,
+                                SplitFix fix) {
+    constexpr int MT = 8, NT = 4, WN = 4, SLOT = 512 * 64, NL = 4;
+    constexpr int kEpiOps = MT * Epi::kMinOps;
+    constexpr int kExtCount = NL + kEpiOps > 63 ? 63 : NL + kEpiOps;
+    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / WN, wn = w % WN;
+    const int ns = K >> 5;
+
+    const int schunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    // DMA sources as a uniform 64-bit base (SGPRs: tile origin + K offset) plus a 32-bit per-lane byte offset that is
+    // the same for every tile (the persistent kernel only takes shapes whose tiles all lie inside the matrices).
+    const char* a_base;
+    const char* w_base;
+    uint32_t a_voff[2], w_voff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int R = (w * 2 + t) * 16 + (lane >> 2), r = R & 63;
+        const int wr = (R & ~63) + ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);   // permuted weight row
+        a_voff[t] = (uint32_t)(R * (int)lda + schunk * 8) * 2u;
+        w_voff[t] = (uint32_t)(wr * (int)ldw + schunk * 8) * 2u;
+    }
+    auto set_src = [&](int64_t m0, int n0) {
+        a_base = (const char*)(A + m0 * lda);
+        w_base = (const char*)(W + (int64_t)n0 * ldw);
+    };
+    // LDS DMA as inline asm (saddr form: uniform base in SGPRs + 32-bit lane offset; M0 = LDS address of the wave's
+    // 1 KiB piece).  Deliberately NOT the __builtin: LLVM's waitcnt pass treats an LDS DMA as a pending "flat" access
+    // and then turns EVERY counted wait it inserts (the lgkmcnt of fragment reads carried across steps, the vmcnt of
+    // epilogue loads) into a wait for zero for as long as a DMA is in flight -- which here is always.  Untracked, the
+    // DMAs only ever make the compiler's own vmcnt waits conservative (they complete in issue order and none is issued
+    // inside an epilogue); the ring's ordering is enforced by the explicit counted waits below.
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma = [&](auto which, int slot, int koff) {
+        constexpr int WH = decltype(which)::value;                     // 0,1: activation rows; 2,3: weight rows
+        const char* sb = (WH < 2 ? a_base : w_base) + koff * 2;
+        const uint32_t vo = WH < 2 ? a_voff[WH & 1] : w_voff[WH & 1];
+        const uint32_t lds = lds0 + slot * SLOT + (WH < 2 ? 0 : 256 * 64) + (w * 2 + (WH & 1)) * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(lds) : "memory");
+    };
+    using D0 = std::integral_constant<int, 0>;
+    using D1 = std::integral_constant<int, 1>;
+    using D2 = std::integral_constant<int, 2>;
+    using D3 = std::integral_constant<int, 3>;
+    auto stage = [&](int slot, int koff) {
+        dma(D0{}, slot, koff); dma(D1{}, slot, koff); dma(D2{}, slot, koff); dma(D3{}, slot, koff);
+    };
+
+    const int fr = lane & 15, kg = lane >> 4;
+    const int sw = (kg ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4;
+    const int x_off = (wm * MT * 16 + fr) * 64 + sw;
+    const int w_off = 256 * 64 + (wn * NT * 16 + fr) * 64 + sw;
+
+    // Register plan (256 per lane at two waves per SIMD): 128 accumulators, the W fragments double-buffered (2 x 16),
+    // the activation fragments SINGLE-buffered (32): the MFMAs run activation-fragment-major, and fragment j of the next
+    // stage is re-read into the same registers once its four MFMAs are issued.  Those reads complete in the following
+    // step, so a slot is recycled one step later than in the per-tile kernel: the DMA of stage s+3 (not s+4) goes into
+    // the slot of stage s-1, whose fragments every wave consumed before this step's barrier -- no LDS wait at the barrier.
+    f32x4 acc[NT][MT];
+    bf16x8 x[MT], wa[NT], wb[NT];
+    // One 32-deep stage s as 16 pairs of MFMAs (pair p: activation fragment p/2, W fragments 2(p&1), 2(p&1)+1), each
+    // pair fenced with ONE memory operation so the matrix pipe never waits for an issue slot:
+    //   W'0 G0 W'1 X'0 G1 W'2 X'1 G2 W'3 X'2 G3 X'3 X'4 X'5 X'6 -- X'7   (' = of stage s+1, G = DMA piece of stage s+3)
+    // X'j follows the last MFMA of fragment j (X'7 trails the last pair; it is not needed before pair 14 of step s+1).
+    // WAITK: 3 = steady state (one stage may stay in flight; plus the previous epilogue's operations when `ext`), 0..2 =
+    // that many stages, 4 / 5 = the last two steps of a tile.  LOADF: read the fragments of stage s+1 (slot fslot).  ISSUE (compile time) and
+    // `more` (run time): start the DMA of stage s+3 into slot islot at element offset koff of the issue pointers.
+    auto step = [&](auto waitk, auto loadf, auto issue, bool ext, bool more, int fslot, int islot, int koff, const bf16x8 (&wc)[NT],
+                    bf16x8 (&wnx)[NT]) {
+        constexpr int WAITK = decltype(waitk)::value;
+        constexpr bool LOADF = decltype(loadf)::value, ISSUE = decltype(issue)::value;
+        if constexpr (WAITK == 3) {
+            if (ext) __builtin_amdgcn_s_waitcnt(vm_imm(kExtCount));
+            else __builtin_amdgcn_s_waitcnt(vm_imm(NL));
+        } else if constexpr (WAITK == 4) {              // second to last step of a tile: steady-state wait, or drain
+            if (more) __builtin_amdgcn_s_waitcnt(vm_imm(NL));
+            else __builtin_amdgcn_s_waitcnt(vm_imm(0));
+        } else if constexpr (WAITK == 5) {              // last step: steady-state wait, or nothing left to wait for
+            if (more) __builtin_amdgcn_s_waitcnt(vm_imm(NL));
+        } else if constexpr (WAITK >= 0) {
+            __builtin_amdgcn_s_waitcnt(vm_imm(WAITK * NL));
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* xs = smem + fslot * SLOT + x_off;
+        const char* ws = smem + fslot * SLOT + w_off;
+        auto rw = [&](int i) { if constexpr (LOADF) wnx[i] = *reinterpret_cast<const bf16x8*>(ws + i * 1024); };
+        auto rx = [&](int j) { if constexpr (LOADF) x[j] = *reinterpret_cast<const bf16x8*>(xs + j * 1024); };
+        auto g = [&](auto which) { if constexpr (ISSUE) { if (more) dma(which, islot, koff); } };
+        auto pair = [&](int p) {
+            const int j = p >> 1, i0 = (p & 1) * 2;
+            acc[i0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0], x[j], acc[i0][j], 0, 0, 0);
+            acc[i0 + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0 + 1], x[j], acc[i0 + 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        rw(0); pair(0);
+        g(D0{}); pair(1);
+        rw(1); pair(2);
+        rx(0); pair(3);
+        g(D1{}); pair(4);
+        rw(2); pair(5);
+        rx(1); pair(6);
+        g(D2{}); pair(7);
+        rw(3); pair(8);
+        rx(2); pair(9);
+        g(D3{}); pair(10);
+        rx(3); pair(11);
+        rx(4); pair(12);
+        rx(5); pair(13);
+        rx(6); pair(14);
+        pair(15);
+        rx(7);
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    int item = blockIdx.x;
+    int tm, tn;
+    tile_coords(item, n_items + n_tail, tiles_m, tiles_n, tm, tn);
+    int64_t m0 = (int64_t)tm * 256;
+    int n0 = tn * 256;
+    set_src(m0, n0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) stage(s, s * 32);
+    __builtin_amdgcn_s_waitcnt(vm_imm(2 * NL));
+    __builtin_amdgcn_s_barrier();
+    bool ext = false;
+    for (;;) {
+        // fragments of this tile's stage 0 (landed: prologue above, or the barrier of the previous tile's last step)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + w_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) x[j] = *reinterpret_cast<const bf16x8*>(smem + x_off + j * 1024);
+        const int nxt = item + (int)gridDim.x;
+        const bool has_next = nxt < n_items;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // steps 0, 1: the epilogue of the previous tile may still be in flight behind stages 1 / 2
+        step(I3{}, T{}, T{}, ext, true, 1, 3, 3 * 32, wa, wb);
+        step(I3{}, T{}, T{}, ext, true, 2, 0, 4 * 32, wb, wa);
+        int s = 2;
+        for (; s + 4 < ns; s += 2) {
+            step(I3{}, T{}, T{}, false, true, (s + 1) & 3, (s + 3) & 3, (s + 3) * 32, wa, wb);
+            step(I3{}, T{}, T{}, false, true, (s + 2) & 3, s & 3, (s + 4) * 32, wb, wa);
+        }
+        // s == ns - 4 (a multiple of 4): stages s .. s+3 sit in slots 0 .. 3; one more step issues a stage of this tile
+        int64_t nm0 = 0;
+        int nn0 = 0;
+        step(I3{}, T{}, T{}, false, true, 1, 3, (s + 3) * 32, wa, wb);
+        if (has_next) {
+            tile_coords(nxt, n_items + n_tail, tiles_m, tiles_n, tm, tn);
+            nm0 = (int64_t)tm * 256;
+            nn0 = tn * 256;
+            set_src(nm0, nn0);
+        }
+        // last three steps: with a next tile they issue its stages 0..2 and wait like steady-state steps (a steady-state
+        // wait is also right for the first of them without one); without, the last two drain the ring
+        // (one code path: two arms that each define the accumulators cost ~330 spilled registers)
+        step(I1{}, T{}, T{}, false, has_next, 2, 0, 0, wb, wa);
+        step(I4{}, T{}, T{}, false, has_next, 3, 1, 32, wa, wb);
+        step(I5{}, F{}, T{}, false, has_next, 0, 2, 64, wb, wa);      // with a next tile: its stage 0 has landed behind this barrier
+        {
+            // launder the lane coordinates so the per-row output addresses are rebuilt here, per tile, instead of being
+            // hoisted out of the tile loop and held (then spilled) across the main loop
+            int fr_e = fr, kg_e = kg;
+            asm volatile("" : "+v"(fr_e), "+v"(kg_e));
+            tile_epilogue<MT, Epi, true>(acc, ep, M, N, n_cover, m0, n0, wm, wn, fr_e, kg_e);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the next fragment reads behind the epilogue (register pressure)
+        if (!has_next) break;
+        ext = true;                                 // every wave issued at least kEpiOps operations in that epilogue
+        item = nxt;
+        m0 = nm0;
+        n0 = nn0;
+    }
+    // Split-K fix-up of a partial last round (see gemm_nt_mfma_tail_kernel): n_items counts the whole rounds only; each of
+    // the n_tail leftover tiles runs as two K halves on two blocks -- producers on blocks [0, n_tail) (they never wait),
+    // consumers on [n_tail, 2 n_tail).  All blocks of this grid are resident, so the consumer's bounded spin is safe.
+    if (n_tail > 0 && (int)blockIdx.x < 2 * n_tail) {
+        const int ns0 = (ns >> 1) & ~1;
+        __builtin_amdgcn_s_waitcnt(vm_imm(0));                 // every DMA of the tile loop has landed before the ring is reused
+        __builtin_amdgcn_s_barrier();
+        if ((int)blockIdx.x < n_tail) {
+            const int t = blockIdx.x;
+            tile_coords(n_items + t, n_items + n_tail, tiles_m, tiles_n, tm, tn);
+            gemm_tile<8, Epi, TILE_PRODUCE>(smem, A, lda, W, ldw, M, N, ns0 * 32, ns - ns0, (int64_t)tm * 256, tn * 256, n_cover, ep, &fix, t);
+        } else {
+            const int t = blockIdx.x - n_tail;
+            tile_coords(n_items + t, n_items + n_tail, tiles_m, tiles_n, tm, tn);
+            gemm_tile<8, Epi, TILE_CONSUME>(smem, A, lda, W, ldw, M, N, 0, ns0, (int64_t)tm * 256, tn * 256, n_cover, ep, &fix, t);
+        }
+    }
 }
 
 // Wave-quantisation fix for grids that are not a whole number of "rounds" of the 256 CUs (o-proj / FFN-down of the
@@ -301,11 +543,42 @@ size_t gemm_fix_header_bytes() { return kFixHeader; }
 template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                         const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes, unsigned fix_epoch, hipStream_t s) {
-    static const int env_tile = [] {                       // experiments only: P2T_GEMM_TILE=128|256 forces a tile height
-        const char* e = getenv("P2T_GEMM_TILE");           //                   P2T_GEMM_TILE=1 disables the split-K tail
-        return e ? atoi(e) : 0;
-    }();
-    if (tile == 0) tile = env_tile;
+    if (tile == 0) {                                       // experiments only: P2T_GEMM_TILE=128|256 forces a tile height,
+        const char* e = getenv("P2T_GEMM_TILE");           // 1 disables the split-K tail, 2 disables the persistent kernel
+        tile = e ? atoi(e) : 0;
+    }
+    {
+        // persistent kernel: shapes without edge tiles and at least one whole round of tiles.  tile: 0 / 3 = with the
+        // split-K fix-up of a partial last round when it is worth it (3: whenever possible), 4 = never
+        const int64_t items = ceil_div(M, 256) * ceil_div(n_cover, 256);
+        const int ns = K >> 5;
+        // measured (profiles/r01_microbench_v4.log): whole rounds -> persistent (+5..13 %); a partial last round with
+        // K >= 4096 -> persistent + split-K fix-up (+2..4 % over the per-tile kernel with the fix-up); K < 4096 -> plain
+        // persistent if there are at least four rounds (QKV: +13 %), else the per-tile kernel (o-proj, 2.5 rounds: the
+        // read-modify-write epilogue gains nothing from persistence and the idle half round costs more)
+        const int64_t rem = items % kCUs;
+        const bool eligible = items >= kCUs && (ns & 3) == 0 && ns >= 12 && M % 256 == 0 && N % 256 == 0 && n_cover == N;
+        const bool pick = tile == 3 || tile == 4 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs));
+        if (eligible && pick) {
+            int64_t n_full = items, n_tail = 0;
+            SplitFix fix{};
+            const bool worth = tile == 3 || ns >= 128;
+            if (tile != 4 && fix_ws && rem > 0 && rem <= 128 && (ns & 7) == 0 && worth && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
+                n_full = items - rem;
+                n_tail = rem;
+                fix.flag = (unsigned*)fix_ws;
+                fix.timeout = (unsigned*)((char*)fix_ws + 1024);
+                fix.slab = (float*)((char*)fix_ws + kFixHeader);
+                fix.epoch = fix_epoch;
+            }
+            gemm_nt_mfma_persist_kernel<Epi><<<dim3(kCUs), 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K,
+                                                                      (int)ceil_div(M, 256), (int)ceil_div(n_cover, 256),
+                                                                      (int)n_full, (int)n_tail, n_cover, ep, fix);
+            P2T_LAUNCH_CHECK();
+            return P2T_OK;
+        }
+        if (tile == 2 || tile == 3 || tile == 4) tile = 0;
+    }
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);
     const double cost128 = (double)ceil_div(tm128 * tn, kCUs) * kSmallTileCost * 1.08;

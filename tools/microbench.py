@@ -43,15 +43,37 @@ def bench_gemm():
         a, w = rand((M, K)), rand((N, K), scale=0.05)
         bias = None if epi == 3 else rand((N,), torch.float32, 0.1)
         out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
-        ms = timeit(lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1))
         ws, ep = ops.gemm_fix_workspace(dev), [0]
 
         def with_tail():
             ep[0] += 1
             ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1, fix_ws=ws, fix_epoch=ep[0])
-        ms2 = timeit(with_tail)
+        res = []
+        for env, fn in (("2", lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1)), ("2", with_tail),
+                        ("4", with_tail), ("3", with_tail), (None, with_tail)):
+            if env is None:
+                os.environ.pop("P2T_GEMM_TILE", None)
+            else:
+                os.environ["P2T_GEMM_TILE"] = env
+            res.append(timeit(fn))
+        os.environ.pop("P2T_GEMM_TILE", None)
         fl = 2.0 * M * N * K / 1e9
-        print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: {ms:8.3f} ms  {fl / ms:8.1f} TF/s | split-K tail {ms2:8.3f} ms {fl / ms2:8.1f} TF/s", flush=True)
+        print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: TF/s per-tile {fl / res[0]:7.1f} | per-tile+splitK {fl / res[1]:7.1f} | "
+              f"persistent {fl / res[2]:7.1f} | persistent+splitK {fl / res[3]:7.1f} | default {fl / res[4]:7.1f} ({res[4]:.3f} ms)", flush=True)
+
+
+def bench_ksweep():
+    """Per-tile fixed cost vs steady-state rate: time = rounds * (a + b*K)."""
+    for epi in (0, 1, 2):
+        for M, N in ((16384, 10240), (16384, 2560)):
+            for K in (256, 512, 1024, 2560, 5120, 10240):
+                a, w = rand((M, K)), rand((N, K), scale=0.05)
+                bias = rand((N,), torch.float32, 0.1)
+                out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
+                ms = timeit(lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1))
+                rounds = (M // 256) * (N // 256) / 256.0
+                print(f"ksweep epi={epi} M={M} N={N} K={K:6d}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s  "
+                      f"per-round {ms * 1e3 / rounds:7.2f} us", flush=True)
 
 
 def bench_attn():
@@ -81,6 +103,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "gemm" in which:
         bench_gemm()
+    if "ksweep" in which:
+        bench_ksweep()
     if "attn" in which:
         bench_attn()
     if "norm" in which:
