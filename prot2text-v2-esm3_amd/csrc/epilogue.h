@@ -36,14 +36,20 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t idx, float p
     return (float)u >= p * 16777216.0f;
 }
 
+// GEMM outputs are hundreds of MB written once and read by a LATER kernel: non-temporal stores keep a round's
+// 32 MB of results from evicting the operand panels out of the 4 MB L2s (measured +1 % on the GEMM average).
+typedef float p2t_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned p2t_u32x4 __attribute__((ext_vector_type(4)));
 template <int W> __device__ __forceinline__ void storeW(float* p, const float (&v)[W]) {
 #pragma unroll
-    for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+    for (int c = 0; c < W; c += 4) {
+        __builtin_nontemporal_store(p2t_f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]}, reinterpret_cast<p2t_f32x4*>(p + c));
+    }
 }
 template <int W> __device__ __forceinline__ void storeW(bf16_t* p, const float (&v)[W]) {
     if constexpr (W == 8) {
-        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                  pack_bf16x2(v[6], v[7]));
+        __builtin_nontemporal_store(p2t_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                                    reinterpret_cast<p2t_u32x4*>(p));
     } else {
         *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libp2t_hip.so")
+# P2T_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("P2T_HIP_LIB") or os.path.join(_HERE, "lib", "libp2t_hip.so")
 
 F32, BF16 = 0, 1
 READOUT = {"last": 0, "mean": 1, "std": 2, "mix": 3}
