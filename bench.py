@@ -190,7 +190,7 @@ def main():
         f = specs.flops_per_sample(esm, llama, ad, Tp, Tt, 16, backward=True)
         value = world * B * args.steps / elapsed
         step_tflops = f["total"] * B * args.steps / elapsed / 1e12          # per GPU
-        # dominant kernel: gemm_nt_mfma_kernel.  algorithmic GEMM FLOPs per sample = linear layers of both towers
+        # dominant kernel: the gemm_nt_mfma* family (one algorithm, three launch forms).  algorithmic GEMM FLOPs per sample = linear layers of both towers
         # + adapter fwd/bwd (everything except the attention score/value products)
         He, Le = esm.hidden_size, esm.num_hidden_layers
         attn_flops = Le * 4 * Tp * Tp * He + min(16, llama.num_hidden_layers) * 2 * (Tt + 1) * Tt * llama.hidden_size
@@ -209,7 +209,7 @@ def main():
                        "algorithmic_tflop_per_sample": round(f["total"] / 1e12, 4),
                        "step_tflops_per_gpu": round(step_tflops, 1), "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                        "loss": round(loss_val, 5)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_mfma_kernel (bf16 16x16x32 MFMA GEMM, all epilogues)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: persistent / per-tile / split-K-tail variants, all epilogues)",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(args.config, B),
                          "launches_per_step": round(launches_step, 1), "avg_launch_ms": round(avg_ms, 4),
