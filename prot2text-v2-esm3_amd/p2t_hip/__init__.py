@@ -8,16 +8,19 @@ scripts/train_contrast.py), implemented on libp2t_hip.so (hand-written HIP for g
                          readout_embeddings, get_sequence_embeddings, get_description_embeddings,
                          teacher_forcing_forward_pass, ContrastiveTrainer)
 
-`synth` and `specs` (pure numpy: synthetic weights/batches, tower shapes) import without the
-library; everything else needs the built .so and a GPU and raises otherwise -- there is no CPU
-fallback.
+`synth` and `specs` (pure numpy: synthetic weights/batches, tower shapes) and the host-side `data`
+(tokeniser, collater, prefetcher) and `training_state` (lr schedule, checkpoint formats) modules import
+without the library; everything else needs the built .so and a GPU and raises otherwise -- there is no
+CPU fallback.
 """
 from . import specs, synth  # noqa: F401
 
 __all__ = ["specs", "synth", "Esm2LlamaInstructConfig", "ModalityAdapterConfig", "ModalityAdapter",
            "Esm2LlamaInstructForCausalLM", "EsmEncoder", "LlamaDecoder", "BatchInfoNCELoss",
            "SegmentedBatchInfoNCELoss", "readout_embeddings", "l2_normalize", "get_sequence_embeddings",
-           "get_description_embeddings", "teacher_forcing_forward_pass", "ContrastiveTrainer", "ops"]
+           "get_description_embeddings", "teacher_forcing_forward_pass", "ContrastiveTrainer", "ops",
+           "EsmSequenceTokenizer", "ContrastiveCollater", "DevicePrefetcher", "CosineWarmupSchedule", "save_checkpoint",
+           "load_model_checkpoint", "load_optimizer_scheduler_checkpoint"]
 
 _LAZY = {
     "Esm2LlamaInstructConfig": "configuration", "ModalityAdapterConfig": "configuration",
@@ -26,6 +29,9 @@ _LAZY = {
     "readout_embeddings": "contrastive", "l2_normalize": "contrastive", "get_sequence_embeddings": "contrastive",
     "get_description_embeddings": "contrastive", "teacher_forcing_forward_pass": "contrastive",
     "ContrastiveTrainer": "contrastive",
+    "EsmSequenceTokenizer": "data", "ContrastiveCollater": "data", "DevicePrefetcher": "data",
+    "CosineWarmupSchedule": "training_state", "save_checkpoint": "training_state",
+    "load_model_checkpoint": "training_state", "load_optimizer_scheduler_checkpoint": "training_state",
 }
 
 

@@ -222,8 +222,9 @@ class ContrastiveTrainer:
     def __init__(self, model, *, lr=2e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=None,
                  num_segments: int = 1, output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
                  temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None,
-                 overlap_streams: bool = False):
+                 overlap_streams: bool = False, schedule=None):
         self.model = model
+        self.schedule = schedule                   # training_state.CosineWarmupSchedule or None (constant lr)
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                        max_norm=math.inf if max_norm is None else max_norm)
         self.num_segments, self.layer, self.readout_fn = num_segments, output_llm_layer, readout_fn
@@ -365,9 +366,15 @@ class ContrastiveTrainer:
         return self.loss
 
     def optimizer_step(self):
+        """clip_grad_norm_ -> AdamW.step -> scheduler.step (train_contrast.py:453-465)."""
         self.step_count += 1
+        hp = dict(self.hp)
+        if self.schedule is not None:
+            hp["lr"] = self.schedule.lr()
         ops.clip_adamw_step(self.p, self.g, self.m, self.v, self.step_count, shadows=[self.w1, None, self.w2, None],
-                            scratch=self.scratch, grad_norm_out=self.grad_norm, **self.hp)
+                            scratch=self.scratch, grad_norm_out=self.grad_norm, **hp)
+        if self.schedule is not None:
+            self.schedule.step()
         return self.grad_norm
 
     def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -387,6 +394,15 @@ class ContrastiveTrainer:
         finally:
             self.train_mode = saved
         return loss
+
+    @torch.no_grad()
+    def sync_from_module(self):
+        """Module parameters (e.g. a checkpoint just loaded) -> fp32 masters and GEMM-layout copies."""
+        ad, c = self.model.adapter, self.c
+        for dst, src in zip(self.p, (ad.fc1.weight, ad.fc1.bias, ad.fc2.weight, ad.fc2.bias)):
+            dst.copy_(src.detach().float())
+        self.w1[:, : c.input_dim].copy_(self.p[0])
+        self.w2[:, : c.intermediate_dim].copy_(self.p[2])
 
     @torch.no_grad()
     def sync_to_module(self):

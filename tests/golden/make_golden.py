@@ -246,9 +246,110 @@ def run_ops(ref):
     print(f"wrote {path}")
 
 
+def tiny_text_tokenizer(words):
+    """A local word-level HF tokenizer (no files, no network) so that the reference collater can run here."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {w: i for i, w in enumerate(["<pad>", "<unk>", "<eos>"] + list(words))}
+    tk = Tokenizer(models.WordLevel(vocab=vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, pad_token="<pad>", unk_token="<unk>", eos_token=" <eos>")
+    tok.chat_template = "{% for m in messages %}{{ m['content'] }} {% endfor %}"
+    return tok
+
+
+def run_collate(ref):
+    """The reference's own Prot2TextLightCollater (dataset/dataloader_light.py:95-290) on a few rows: the cropped
+    sequences and the description ids / masks are what p2t_hip.data.ContrastiveCollater must reproduce.  The collater's
+    `_calculate_sequence_length` needs the absent `esm` package; it only sizes the chat prompt (not compared here), so
+    that one method is replaced on the instance by len + 2."""
+    import json
+    import random
+    from dataset import Prot2TextLightCollater
+    words = "binds atp and catalyzes the transfer of phosphate to serine residues in membrane proteins kinase".split()
+    nan = float("nan")
+    rows = [
+        {"AlphaFoldDB": "P1", "Full Name": "Kinase A", "taxon": "Homo sapiens", "sequence": "MKTAYIAKQRQISFVKSHFSRQLEERLGLIEV",
+         "function": "binds atp and catalyzes the transfer of phosphate"},
+        {"AlphaFoldDB": "P2", "Full Name": nan, "taxon": "Mus musculus", "sequence": "MSTNPKPQRKTK", "function": "kinase"},
+        {"AlphaFoldDB": "P3", "Full Name": "Membrane protein", "taxon": nan,
+         "sequence": "MALWMRLLPLLALLALWGPDPAAAFVNQHLCGSHLVEALYLVCGERGFFYTPKT",
+         "function": "membrane proteins binds atp in serine residues and the kinase catalyzes transfer of phosphate to proteins"},
+        {"AlphaFoldDB": "P4", "Full Name": "X", "taxon": "E coli", "sequence": "MKVLAAG", "function": "unknownword binds atp"},
+        {"AlphaFoldDB": "P5", "Full Name": nan, "taxon": nan, "sequence": "MGSSHHHHHHSSGLVPRGSHMASMTGG", "function": "transfer of phosphate to serine"},
+    ]
+    params = dict(max_sequence_length=20, max_description_length=8, name_dropout=0.8, taxonomy_dropout=0.8)
+    tok = tiny_text_tokenizer(words)
+    col = Prot2TextLightCollater(description_tokenizer=tok, esm_tokenizer=None, mode="train", **params)
+    col._calculate_sequence_length = lambda seq: len(seq) + 2
+    expected = []
+    for seed in (0, 1, 2):
+        random.seed(seed)
+        b = col(rows)
+        expected.append({"seed": seed, "protein_sequences": b["protein_sequences"],
+                         "description_input_ids": b["description_input_ids"].tolist(),
+                         "description_attention_mask": b["description_attention_mask"].tolist()})
+    path = os.path.join(HERE, "collate.json")
+    rows_json = [{k: (None if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+    with open(path, "w") as f:
+        json.dump({"words": words, "rows": rows_json, "params": params, "expected": expected}, f, indent=1)
+    print(f"wrote {path}")
+
+
+def run_train_state(ref):
+    """Four optimizer steps of the reference's training recipe on the tiny model (train_contrast.py:417-465, 621-637):
+    AdamW over model.parameters() + HF cosine schedule with warm-up, loss through the reference's readout / InfoNCE,
+    dropout 0 for determinism.  Stores the per-step loss and lr, the final adapter tensors, the parameter order and the
+    optimizer / scheduler state dicts in the format train_contrast.py:692-698 saves."""
+    import json
+    from transformers import get_cosine_schedule_with_warmup
+    tc = ref.tc
+    F = torch.nn.functional
+    esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+    llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,
+                            num_key_value_heads=2, vocab_size=512)
+    ad = specs.AdapterSpec(64, 96, 64, 0.0)
+    B, T_p, T_t, layer = 4, 24, 12, 2
+    model = build_reference_model(ref, esm, llama, ad, 0)
+    model.adapter.requires_grad_(True)
+    model.adapter.train()
+    names = [n for n, _ in model.named_parameters()]
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, eps=1e-6, betas=(0.9, 0.999))
+    total_steps, warmup = 10, 2
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=warmup, num_training_steps=total_steps)
+    shim = types.SimpleNamespace(llm_decoder=model.llama_decoder)
+    out = {"losses": [], "lrs": []}
+    for step in range(4):
+        pid, pmask = synth.protein_batch(100 + step, B, T_p, [24, 15, 7, 3])
+        tid, tmask = synth.text_batch(100 + step, B, T_t, 500, [12, 9, 5, 2], 510, 509)
+        pid_t, pmask_t, tid_t, tmask_t = (torch.from_numpy(a) for a in (pid, pmask, tid, tmask))
+        with torch.no_grad():
+            t = F.normalize(tc.get_description_embeddings(shim, tid_t, tmask_t, output_llm_layer=layer), p=2, dim=-1)
+        ad_out, _ = model(protein_input_ids=pid_t, protein_attention_mask=pmask_t, return_adapter_outputs=True)
+        p = F.normalize(tc.readout_embeddings(ad_out, pmask_t, "mix"), p=2, dim=-1)
+        loss = tc.SegmentedBatchInfoNCELoss()(p, t, torch.arange(B))
+        out["lrs"].append(opt.param_groups[0]["lr"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float("inf"))
+        opt.step()
+        sched.step()
+        opt.zero_grad(set_to_none=True)
+        out["losses"].append(float(loss))
+    final = {n: prm.detach().clone() for n, prm in model.adapter.named_parameters()}
+    torch.save({"optimizer_state_dict": opt.state_dict(), "scheduler_state_dict": sched.state_dict()},
+               os.path.join(HERE, "train_state_optimizer_scheduler.pt"))
+    torch.save(final, os.path.join(HERE, "train_state_model.pt"))
+    meta = dict(param_names=names, losses=out["losses"], lrs=out["lrs"], lr=1e-3, total_steps=total_steps, warmup=warmup,
+                B=B, T_p=T_p, T_t=T_t, layer=layer, esm=specs.spec_dict(esm), llama=specs.spec_dict(llama),
+                adapter=specs.spec_dict(ad))
+    with open(os.path.join(HERE, "train_state.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote train_state.json / train_state_model.pt / train_state_optimizer_scheduler.pt", out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,cfg1")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,cfg1,collate,train_state")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -256,6 +357,10 @@ def main():
     ref = load_reference()
     if "ops" in only:
         run_ops(ref)
+    if "collate" in only:
+        run_collate(ref)
+    if "train_state" in only:
+        run_train_state(ref)
     if "tiny" in only:
         esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
         llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,

@@ -1,0 +1,97 @@
+"""Host-side batch pipeline: tokeniser vs the installed HF EsmTokenizer, collater vs the
+reference's own Prot2TextLightCollater (tests/golden/collate.json, written by make_golden.py), prefetcher ordering."""
+import json
+import os
+import random
+
+import pytest
+import torch
+
+from p2t_hip import data
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tiny_text_tokenizer(words):
+    """Same local word-level tokenizer the golden script gave the reference collater."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {w: i for i, w in enumerate(["<pad>", "<unk>", "<eos>"] + list(words))}
+    tk = Tokenizer(models.WordLevel(vocab=vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    return PreTrainedTokenizerFast(tokenizer_object=tk, pad_token="<pad>", unk_token="<unk>", eos_token=" <eos>")
+
+
+@pytest.fixture(scope="module")
+def hf_esm_tokenizer(tmp_path_factory):
+    from transformers import EsmTokenizer
+    path = tmp_path_factory.mktemp("esm") / "vocab.txt"
+    path.write_text("\n".join(data.ESM_VOCAB) + "\n")
+    return EsmTokenizer(str(path))
+
+
+def test_esm_vocab_ids():
+    tok = data.EsmSequenceTokenizer()
+    assert len(data.ESM_VOCAB) == 33
+    assert (tok.cls_token_id, tok.pad_token_id, tok.eos_token_id, tok.unk_token_id, tok.mask_token_id) == (0, 1, 2, 3, 32)
+
+
+def test_esm_tokenizer_matches_hf(hf_esm_tokenizer):
+    tok = data.EsmSequenceTokenizer()
+    fixed = ["MKTAYIAKQR", "AJJB", "AjB", "A B", "AC-.XZ", "", "M<mask>K", "JJJ", "AJ J", "<cls>A<eos>", "<A", "A<", "<null_1>",
+             "  M  K ", "UZOBX"]
+    rng = random.Random(5)
+    alphabet = "LAGVSERTIDPKQNFYMHWCXBUZO.-" + "Jj1 <>"
+    rand = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 60))) for _ in range(300)]
+    for s in fixed + rand:
+        want = hf_esm_tokenizer([s], add_special_tokens=True, return_attention_mask=False)["input_ids"][0]
+        assert tok.encode(s) == want, repr(s)
+        want_ns = hf_esm_tokenizer([s], add_special_tokens=False, return_attention_mask=False)["input_ids"][0]
+        assert tok.encode(s, add_special_tokens=False) == want_ns, repr(s)
+
+
+def test_esm_batch_padding_matches_hf(hf_esm_tokenizer):
+    seqs = ["MKTAYIAKQRQISFVKSHFSRQ", "MK", "", "ACDEFGHIKLMNPQRSTVWY"]
+    got = data.EsmSequenceTokenizer()(seqs)
+    want = hf_esm_tokenizer(seqs, padding=True, return_tensors="pt")
+    assert torch.equal(got["input_ids"], want["input_ids"]) and torch.equal(got["attention_mask"], want["attention_mask"])
+    assert got["input_ids"].dtype == torch.int64 and got["input_ids"][1, 4:].eq(1).all()
+
+
+def test_pad_sequences():
+    a, b = torch.tensor([1, 2, 3]), torch.tensor([4])
+    assert data.pad_sequences([a, b], 9, "right").tolist() == [[1, 2, 3], [4, 9, 9]]
+    assert data.pad_sequences([a, b], -100, "left").tolist() == [[1, 2, 3], [-100, -100, 4]]
+    with pytest.raises(ValueError):
+        data.pad_sequences([a, b], 0, "middle")
+
+
+def test_collater_matches_reference_golden():
+    with open(os.path.join(HERE, "golden", "collate.json")) as f:
+        g = json.load(f)
+    rows = [{k: (float("nan") if v is None else v) for k, v in r.items()} for r in g["rows"]]
+    col = data.ContrastiveCollater(tiny_text_tokenizer(g["words"]), **g["params"])
+    seq_tok = data.EsmSequenceTokenizer()
+    for exp in g["expected"]:
+        random.seed(exp["seed"])
+        b = col(rows)
+        assert b["protein_sequences"] == exp["protein_sequences"]                        # same random crop windows
+        assert b["description_input_ids"].tolist() == exp["description_input_ids"]
+        assert b["description_attention_mask"].tolist() == exp["description_attention_mask"]
+        assert b["name"] == [r["AlphaFoldDB"] for r in rows]
+        # protein half of the contract: <cls> seq <eos>, right padded with id 1 (dataset/dataloader.py:113-123)
+        want = seq_tok(exp["protein_sequences"])
+        assert torch.equal(b["protein_input_ids"], want["input_ids"])
+        assert torch.equal(b["protein_attention_mask"], want["attention_mask"])
+        assert b["protein_input_ids"].shape[1] == g["params"]["max_sequence_length"] + 2
+        assert b["description_input_ids"].shape[1] <= g["params"]["max_description_length"]
+    crops = {tuple(e["protein_sequences"]) for e in g["expected"]}
+    assert len(crops) > 1                                                               # the seeds really differ
+
+
+def test_prefetcher_keeps_order_and_content():
+    batches = [{"protein_input_ids": torch.full((2, 3), i), "name": [f"n{i}"]} for i in range(5)]
+    seen = list(data.DevicePrefetcher(batches, "cpu", transform=lambda b: {**b, "extra": b["protein_input_ids"] + 1}))
+    assert [b["name"][0] for b in seen] == [f"n{i}" for i in range(5)]
+    assert all(int(b["extra"][0, 0]) == i + 1 for i, b in enumerate(seen))
+    assert list(data.DevicePrefetcher([], "cpu")) == []

@@ -1,0 +1,111 @@
+"""Training recipe and checkpoints on the GPU: four optimizer steps of ContrastiveTrainer
+with the cosine schedule against the reference's recipe (tests/golden/train_state*.{json,pt}: AdamW over
+model.parameters() + HF warm-up/cosine + the reference loss, make_golden.py run_train_state), the checkpoint files in
+both directions, and resume-equals-continue."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import build_model, rel, to_dev, to_np
+from p2t_hip import specs, synth
+from p2t_hip import training_state as ts
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAMES = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+
+
+def _meta():
+    with open(os.path.join(HERE, "golden", "train_state.json")) as f:
+        return json.load(f)
+
+
+def _batch(meta, step):
+    pid, pmask = synth.protein_batch(100 + step, meta["B"], meta["T_p"], [24, 15, 7, 3])
+    tid, tmask = synth.text_batch(100 + step, meta["B"], meta["T_t"], 500, [12, 9, 5, 2], 510, 509)
+    return {"protein_input_ids": to_dev(pid), "protein_attention_mask": to_dev(pmask),
+            "description_input_ids": to_dev(tid), "description_attention_mask": to_dev(tmask)}
+
+
+def _trainer(meta, steps=0):
+    import p2t_hip as P
+    esm, llama, ad = (specs.EsmSpec(**meta["esm"]), specs.LlamaSpec(**meta["llama"]), specs.AdapterSpec(**meta["adapter"]))
+    model = build_model(esm, llama, ad, torch.float32, 0)
+    model.train()
+    sched = ts.CosineWarmupSchedule(meta["lr"], meta["warmup"], meta["total_steps"])
+    tr = P.ContrastiveTrainer(model, lr=meta["lr"], schedule=sched, output_llm_layer=meta["layer"], train_mode=True)
+    losses, lrs = [], []
+    for s in range(steps):
+        lrs.append(sched.lr())
+        losses.append(float(to_np(tr.step(_batch(meta, s)))[0]))
+    return tr, losses, lrs
+
+
+def test_parameter_order_matches_reference():
+    """torch keys optimizer state by position in model.parameters(): the module tree must enumerate like upstream's."""
+    meta = _meta()
+    tr, _, _ = _trainer(meta)
+    assert [n for n, _ in tr.model.named_parameters()] == meta["param_names"]
+    assert ts.adapter_param_indices(tr.model) == [meta["param_names"].index(n) for n in ts.ADAPTER_PARAM_NAMES]
+
+
+def test_four_steps_match_reference_recipe(tmp_path):
+    meta = _meta()
+    tr, losses, lrs = _trainer(meta, steps=4)
+    assert lrs == pytest.approx(meta["lrs"], rel=1e-12, abs=1e-18)
+    assert losses == pytest.approx(meta["losses"], rel=2e-4)
+    ref_model = torch.load(os.path.join(HERE, "golden", "train_state_model.pt"), weights_only=True)
+    for t, n in zip(tr.p, NAMES):
+        np.testing.assert_allclose(to_np(t), ref_model[n].numpy(), rtol=2e-4, atol=2e-6)
+    ref = torch.load(os.path.join(HERE, "golden", "train_state_optimizer_scheduler.pt"), weights_only=True)
+    mine = ts.optimizer_state_dict(tr)
+    assert sorted(mine["state"]) == sorted(ref["optimizer_state_dict"]["state"])
+    for i in mine["state"]:
+        a, b = mine["state"][i], ref["optimizer_state_dict"]["state"][i]
+        assert float(a["step"]) == float(b["step"]) == 4
+        assert rel(a["exp_avg"].numpy(), b["exp_avg"].numpy()) < 1e-3
+        assert rel(a["exp_avg_sq"].numpy(), b["exp_avg_sq"].numpy()) < 1e-3
+    ga, gb = mine["param_groups"][0], ref["optimizer_state_dict"]["param_groups"][0]
+    assert set(ga) == set(gb) and ga["params"] == gb["params"]
+    for k in ("lr", "eps", "weight_decay", "initial_lr"):
+        assert ga[k] == pytest.approx(gb[k], rel=1e-12)
+    assert tuple(ga["betas"]) == tuple(gb["betas"])
+    sa, sb = tr.schedule.state_dict(), ref["scheduler_state_dict"]
+    assert set(sa) == set(sb) and sa["last_epoch"] == sb["last_epoch"] and sa["_step_count"] == sb["_step_count"]
+    assert sa["_last_lr"][0] == pytest.approx(sb["_last_lr"][0], rel=1e-12)
+    # our files: the upstream names, loadable with the safe loader, adapter file has upstream's eight keys
+    paths = ts.save_checkpoint(tr, str(tmp_path), 7)
+    assert [os.path.basename(p) for p in paths] == ["model_checkpoint_7.pt", "optimizer_scheduler_checkpoint_7.pt"]
+    sd = torch.load(paths[0], weights_only=True)
+    assert sorted(sd) == sorted(ref_model)
+    for n in NAMES:
+        np.testing.assert_allclose(sd[n].numpy(), ref_model[n].numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_resume_from_reference_checkpoint_equals_continuing(tmp_path):
+    """A fresh trainer that loads the REFERENCE's files continues exactly like the trainer that ran the four steps
+    itself would from the same state; and resuming from our own files is bit-identical to not stopping."""
+    meta = _meta()
+    cont, _, _ = _trainer(meta, steps=4)
+    own = ts.save_checkpoint(cont, str(tmp_path), 1)
+    loss_cont = float(to_np(cont.step(_batch(meta, 4)))[0])
+    res, _, _ = _trainer(meta)
+    ts.load_model_checkpoint(res.model, own[0], trainer=res)
+    ts.load_optimizer_scheduler_checkpoint(res, own[1])
+    assert res.step_count == 4 and res.schedule.last_epoch == 4
+    loss_res = float(to_np(res.step(_batch(meta, 4)))[0])
+    assert loss_res == loss_cont
+    for a, b in zip(res.p + res.m + res.v, cont.p + cont.m + cont.v):
+        assert torch.equal(a, b)
+    ref_tr, _, _ = _trainer(meta)
+    ts.load_model_checkpoint(ref_tr.model, os.path.join(HERE, "golden", "train_state_model.pt"), trainer=ref_tr)
+    ts.load_optimizer_scheduler_checkpoint(ref_tr, os.path.join(HERE, "golden", "train_state_optimizer_scheduler.pt"))
+    ref_sched = torch.load(os.path.join(HERE, "golden", "train_state_optimizer_scheduler.pt"), weights_only=True)["scheduler_state_dict"]
+    assert ref_tr.step_count == 4 and ref_tr.schedule.lr() == pytest.approx(ref_sched["_last_lr"][0], rel=1e-12)
+    loss_ref = float(to_np(ref_tr.step(_batch(meta, 4)))[0])
+    assert loss_ref == pytest.approx(loss_cont, rel=2e-4)
+    for a, b in zip(ref_tr.p, cont.p):
+        np.testing.assert_allclose(to_np(a), to_np(b), rtol=2e-4, atol=2e-6)
