@@ -118,7 +118,7 @@ def pmc_traffic(cfg_name, batch):
         return None
     try:
         with open(path) as f:
-            return round(json.load(f)["kernels"]["gemm_nt_mfma_kernel"]["hbm_bytes_per_launch"])
+            return round(json.load(f)["kernels"]["gemm_nt_mfma*"]["hbm_bytes_per_launch"])
     except (KeyError, ValueError):
         return None
 
