@@ -9,7 +9,7 @@
 // fragment holds key pi(i), pi = swap bits 2 and 3 -- a pure address permutation.
 // K and V are both row-major [keys][dp] in HBM and in LDS; the V^T operand is produced by the
 // hardware transpose read ds_read_b64_tr_b16 (technique T10), so no transposed copy of V exists.
-// K / V tiles are staged with global_load_lds (double buffered), the bank swizzle applied on the
+// K / V tiles are staged with global_load_lds (three LDS buffers, two tiles in flight), the bank swizzle applied on the
 // source address and on the reads (rule 21): 16-B chunk c of row r is stored at c ^ g(r) with
 //   dp = 32: g = (r >> 2) & 3      dp = 64: g = ((r >> 1) & 1) << 2 | (r >> 2) & 3      dp = 128: g = (r & 3) << 2 | (r >> 2) & 3
 // which is conflict-free both for the 32-row ds_read_b128 fragment pattern (K) and for the 4-row x 64-byte
@@ -51,19 +51,37 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
     constexpr int NI = DP / 32;                // glds instructions per wave per tile
     constexpr int DK = DP / 16;                // QK^T k-steps
     constexpr int DT = DP / 32;                // O^T row tiles
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int NBUF = DP == 128 ? 2 : 3;    // K/V tiles in LDS: the one being read + NBUF-1 in flight (96 KiB would
+                                               // leave one block per CU at dp = 128)
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware block order (1-D grid; consecutive ids go round-robin over the 8 XCDs): the q-tiles of one (batch, head)
+    // re-read the same K / V, so they must share an L2 -- heads are dealt to the XCDs in groups of eight and an XCD walks
+    // the q-tiles of its head back to back.  (With q-tile as the fastest grid index every q-tile of a head landed on a
+    // different XCD and K / V crossed the fabric eight times: 1.07 GB per launch measured against 0.25 GB of operands.)
+    const int n_qt = (seq + 127) >> 7, n_hb = nh * B, hb_full = n_hb & ~7;
+    const int id = blockIdx.x;
+    int qt, hb;
+    if (id < hb_full * n_qt) {
+        const int slot = id >> 3;
+        hb = (slot / n_qt) * 8 + (id & 7);
+        qt = slot % n_qt;
+    } else {
+        const int rid = id - hb_full * n_qt;
+        hb = hb_full + rid / n_qt;
+        qt = rid % n_qt;
+    }
+    const int h = hb % nh, b = hb / nh;
     const int hk = h / (nh / nkv);
-    const int q0 = blockIdx.x * 128 + w * 32;
+    const int q0 = qt * 128 + w * 32;
     const int lq = lane & 31, hh = lane >> 5;
     const int query = q0 + lq;
 
     int end = kv_info[b];
     const int prefix = kv_info[B + b];
-    if (causal) end = min(end, (int)blockIdx.x * 128 + 128);
+    if (causal) end = min(end, qt * 128 + 128);
     const int n_it = (end + 63) >> 6;
 
     const bf16_t* kbase = k + ((int64_t)(b * nkv + hk) * seq) * DP;
@@ -77,21 +95,40 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int kk = 0; kk < DK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
     }
+    // the Q loads are the only vector-memory operations the compiler tracks: waited for here, ahead of the loop, so that
+    // no vmcnt wait of its own lands inside a step (there it would also wait for the untracked DMA of the next tile);
+    // passing the fragments through an empty asm makes the compiler place that wait here
+#pragma unroll
+    for (int kk = 0; kk < DK; ++kk) asm volatile("" : "+v"(qf[kk]));
 
-    // ---- staging (global_load_lds, 1 KiB per wave instruction); K and V tiles share the layout ----
+    // ---- staging (LDS DMA, 1 KiB per wave instruction); K and V tiles share the layout ----
+    // Issued from inline asm (saddr form: uniform tile base + 32-bit lane offset, M0 = LDS address) rather than through
+    // the builtin: while a builtin LDS DMA is pending LLVM's waitcnt pass turns every wait it inserts into a wait for
+    // zero on BOTH counters -- each K fragment read was waited for individually and a vmcnt(0) landed in the middle of
+    // the step, i.e. the "prefetch" of the next tile was waited for before the softmax.  The explicit vmcnt(0) at the
+    // top of each step is what orders the DMA against the reads.
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t s_voff[NI];
+    int s_row[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int byte = (w + 4 * i) * 1024 + lane * 16;
+        const int row = byte / RB, p = (byte % RB) >> 4;
+        s_row[i] = row;
+        s_voff[i] = (uint32_t)(row * RB + ((p ^ swz_g<DP>(row)) << 4));
+    }
     auto stage = [&](int buf, int it) {
         const int kb = it * 64;
-        char* sb = smem + buf * STAGE;
+        const uint32_t sb = lds0 + buf * STAGE;
+        const char* kt = (const char*)(kbase + (int64_t)kb * DP);
+        const char* vt = (const char*)(vbase + (int64_t)kb * DP);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int ii = w + 4 * i;
-            const int byte = ii * 1024 + lane * 16;
-            const int row = byte / RB, p = (byte % RB) >> 4;
-            const int c = p ^ swz_g<DP>(row);
-            int key = kb + row;
-            key = key < seq ? key : seq - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (int64_t)key * DP + c * 8), (lptr_t)(sb + ii * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(vbase + (int64_t)key * DP + c * 8), (lptr_t)(sb + T_BYTES + ii * 1024), 16, 0, 0);
+            // rows past the end of the sequence re-read its last row (their scores are masked)
+            const uint32_t vo = kb + s_row[i] < seq ? s_voff[i] : (uint32_t)((seq - 1 - kb) * RB) + (s_voff[i] - (uint32_t)(s_row[i] * RB));
+            const uint32_t lk = sb + (w + 4 * i) * 1024, lv = lk + T_BYTES;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(kt), "s"(lk) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(vt), "s"(lv) : "memory");
         }
     };
 
@@ -133,9 +170,12 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto step = [&](auto bufc, int it) {
         constexpr int BUF = decltype(bufc)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it + 1 < n_it) stage(BUF ^ 1, it + 1);
+        // tile `it` has landed (this wave's pieces: counted wait, with three buffers the next tile's 2 NI pieces may stay in
+        // flight; all waves': the barrier), and every wave is done reading the buffer the new tile goes into (it held tile it-1)
+        if (NBUF == 3 && it + 1 < n_it) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NI));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        if (it + NBUF - 1 < n_it) stage((BUF + NBUF - 1) % NBUF, it + NBUF - 1);
         const char* sb = smem + BUF * STAGE;
         const int kb = it * 64;
 
@@ -181,10 +221,24 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[t][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);                      // running max of the RAW scores
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;       // fully masked so far: p = exp2(-inf) = 0
-        const float mc = m_use * scale_log2e;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2e);   // m_run = -inf -> 0
+        // Lazy rescale: the reference point m_run of the exponentials only moves when some query of this wave saw a score
+        // more than kSlack (in log2 units of the scaled scores) above it; otherwise p = exp2(scale (s - m_run)) <= 2^kSlack,
+        // harmless in fp32 / bf16, and the 32 accumulator multiplies + the alpha exponential are skipped (wave-uniform
+        // branch).  The result is unchanged up to rounding: numerator and denominator carry the same reference.
+        constexpr float kSlack = 8.0f;
+        const bool grow = mloc != -INFINITY && (m_run == -INFINITY || (mloc - m_run) * scale_log2e > kSlack);
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+            const float m_new = fmaxf(m_run, mloc);                  // running reference of the RAW scores
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;   // fully masked so far: p = exp2(-inf) = 0
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2e);   // m_run = -inf -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = (m_run == -INFINITY ? 0.f : m_run) * scale_log2e;
         float lsum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -195,12 +249,7 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
                 lsum += p;
             }
         lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        l_run += lsum;
         // O^T += V^T . P^T
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
@@ -218,9 +267,13 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
         }
     };
     if (n_it > 0) stage(0, 0);
-    for (int it = 0; it < n_it; it += 2) {
+    if (NBUF == 3 && n_it > 1) stage(1, 1);
+    for (int it = 0; it < n_it; it += NBUF) {
         step(std::integral_constant<int, 0>{}, it);
         if (it + 1 < n_it) step(std::integral_constant<int, 1>{}, it + 1);
+        if constexpr (NBUF == 3) {
+            if (it + 2 < n_it) step(std::integral_constant<int, 2>{}, it + 2);
+        }
     }
 
     // ---- epilogue: O^T rows = channels (r&3) + 8(r>>2) + 4hh, col = query ----
@@ -251,7 +304,7 @@ int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t*
                      hipStream_t s) {
     P2T_REQUIRE(d % 4 == 0 && (dp == 32 || dp == 64 || dp == 128) && d <= dp && nh % nkv == 0 && (nh * d) % 4 == 0 && ld_out % 4 == 0,
                 "attention(mfma): unsupported shape d=%d dp=%d heads %d/%d", d, dp, nh, nkv);
-    const dim3 grid((unsigned)ceil_div(T, 128), (unsigned)nh, (unsigned)B);
+    const dim3 grid((unsigned)(ceil_div(T, 128) * nh * B));
     const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
     const float sl = scale * 1.4426950408889634f;
 #define P2T_ATTN(DPV)                                                                                              \
