@@ -180,6 +180,35 @@ int p2t_llama_hidden_forward(const p2t_llama_config* cfg, const p2t_llama_weight
                              const int64_t* mask, int B, int T, int k, float* out, void* workspace,
                              size_t workspace_bytes, p2t_stream stream);
 
+/* Same tower from caller-supplied layer-0 inputs (f32 [B*T, hidden]) instead of token ids: the decoder half of
+ * Esm2LlamaInstructForCausalLM.forward, models/modeling_esm2llama_instruct.py:204-215 (`inputs_embeds=...`). */
+int p2t_llama_hidden_forward_embeds(const p2t_llama_config* cfg, const p2t_llama_weights* w, const float* inputs_embeds,
+                                    const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                                    size_t workspace_bytes, p2t_stream stream);
+/* llama_decoder.get_input_embeddings()(input_ids), models/modeling_esm2llama_instruct.py:134: f32 [n_tokens, hidden]. */
+int p2t_llama_embed_tokens(const p2t_llama_config* cfg, const p2t_llama_weights* w, const int64_t* ids, int64_t n_tokens,
+                           float* out, p2t_stream stream);
+
+/* ---------------------------------------------------------------- decoder inputs + LM loss (SFT forward) */
+/* Flat positions, in array order, of the elements with value == match (mode 0) or value != 0 (mode 1): the order in
+ * which torch's boolean-mask indexing enumerates them (`input_ids == placeholder_id`, `encoder_attention_mask.bool()`,
+ * models/modeling_esm2llama_instruct.py:136-137).  pos: int32 [n] (capacity), count: int32 [1]; both on the device. */
+int p2t_positions_where(const int64_t* values, int64_t n, int mode, int64_t match, int32_t* pos, int32_t* count,
+                        p2t_stream stream);
+/* dst[dst_pos[r], :H] = src[src_pos[r], :H] for r < min(*n_dst, *n_src)  (`inputs_embeds[placeholder_mask] =
+ * encoder_hidden_states[encoder_mask]`, :138).  dst f32, src `src_dtype`; counts are read on the device (no host sync;
+ * the caller compares them afterwards to raise torch's shape-mismatch error). */
+int p2t_scatter_rows(float* dst, int64_t ld_dst, const int32_t* dst_pos, const void* src, int64_t ld_src, int src_dtype,
+                     const int32_t* src_pos, const int32_t* n_dst, const int32_t* n_src, int64_t max_rows, int H,
+                     p2t_stream stream);
+/* HF causal-LM loss (transformers loss_utils.ForCausalLMLoss as called by LlamaForCausalLM.forward with labels): logits
+ * `dtype` [B*T, ld >= V]; position (b, t) predicts labels[b, t+1]; targets equal to ignore_index (and out-of-range ones)
+ * are skipped; loss = mean over the rest in f32 (NaN when there is none).  row_loss f32 [B*T], row_valid int32 [B*T]
+ * are outputs as well (deterministic two-stage reduction); count may be NULL. */
+int p2t_cross_entropy_shifted(const void* logits, int64_t ld, int dtype, const int64_t* labels, int B, int T, int V,
+                              int64_t ignore_index, float* row_loss, int32_t* row_valid, float* loss, int32_t* count,
+                              p2t_stream stream);
+
 /* ---------------------------------------------------------------- ModalityAdapter */
 typedef struct {
     int32_t input_dim, intermediate_dim, output_dim;

@@ -148,14 +148,16 @@ extern "C" size_t p2t_llama_workspace_bytes(const p2t_llama_config* cfg, int B, 
     return llama_plan(cfg, B, T, nullptr, nullptr);
 }
 
-extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids,
-                                        const int64_t* mask, int B, int T, int k, float* out, void* workspace,
-                                        size_t workspace_bytes, p2t_stream stream) {
-    P2T_REQUIRE(c && w && ids && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
+// ids != nullptr: token embedding lookup; else inputs_embeds (f32 [B*T, hidden]) is the layer-0 input (SFT path:
+// placeholder positions already replaced by adapter outputs, reference models/modeling_esm2llama_instruct.py:195-215)
+static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, const float* inputs_embeds,
+                              const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                              size_t workspace_bytes, p2t_stream stream) {
+    P2T_REQUIRE(c && w && (ids || inputs_embeds) && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
     P2T_REQUIRE(k >= 0 && k <= c->n_layers, "p2t_llama_hidden_forward: hidden_states[%d] out of range for %d layers", k, c->n_layers);
     P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 32 == 0,
                 "p2t_llama_hidden_forward: unsupported shape");
-    P2T_REQUIRE(w->embed && (k == 0 || w->layers) && (k < c->n_layers || w->final_norm_w), "p2t_llama_hidden_forward: missing weights");
+    P2T_REQUIRE((w->embed || !ids) && (k == 0 || w->layers) && (k < c->n_layers || w->final_norm_w), "p2t_llama_hidden_forward: missing weights");
     P2T_REQUIRE(workspace_bytes >= p2t_llama_workspace_bytes(c, B, T), "p2t_llama_hidden_forward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Arena ar(workspace, workspace_bytes);
@@ -168,7 +170,11 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
     const int64_t NQKV = (int64_t)(nh + 2 * nkv) * d, QO = round_up((int64_t)nh * d, 64);
 
     P2T_TRY(launch_mask_prepare(nullptr, mask, B, T, -1, 0, b.key_mask, b.kv_info, nullptr, s));
-    P2T_TRY(launch_llama_embed(ids, w->embed, dt, (int)H, c->vocab, b.x, M, s));
+    if (ids) {
+        P2T_TRY(launch_llama_embed(ids, w->embed, dt, (int)H, c->vocab, b.x, M, s));
+    } else {
+        P2T_CHECK_HIP(hipMemcpyAsync(b.x, inputs_embeds, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
+    }
     const float* inv_freq = w->inv_freq;
     if (!inv_freq) {
         P2T_TRY(launch_inv_freq(b.inv_freq, d / 2, c->rope_theta, c->rope_llama3, c->rope_factor, c->rope_low_freq_factor,
@@ -201,4 +207,24 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
     if (k == c->n_layers) return launch_rmsnorm(b.x, H, w->final_norm_w, c->rms_norm_eps, out, H, M, H, P2T_F32, s);
     P2T_CHECK_HIP(hipMemcpyAsync(out, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
     return P2T_OK;
+}
+
+extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids,
+                                        const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                                        size_t workspace_bytes, p2t_stream stream) {
+    P2T_REQUIRE(ids, "p2t_llama_hidden_forward: null ids");
+    return llama_forward_impl(c, w, ids, nullptr, mask, B, T, k, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int p2t_llama_hidden_forward_embeds(const p2t_llama_config* c, const p2t_llama_weights* w, const float* inputs_embeds,
+                                               const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                                               size_t workspace_bytes, p2t_stream stream) {
+    P2T_REQUIRE(inputs_embeds, "p2t_llama_hidden_forward_embeds: null inputs_embeds");
+    return llama_forward_impl(c, w, nullptr, inputs_embeds, mask, B, T, k, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int p2t_llama_embed_tokens(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, int64_t n_tokens,
+                                      float* out, p2t_stream stream) {
+    P2T_REQUIRE(c && w && w->embed && ids && out && n_tokens > 0, "p2t_llama_embed_tokens: null/empty argument");
+    return launch_llama_embed(ids, w->embed, c->dtype, c->hidden, c->vocab, out, n_tokens, (hipStream_t)stream);
 }

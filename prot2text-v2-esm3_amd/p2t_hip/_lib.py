@@ -101,6 +101,12 @@ SIGNATURES = {
     "p2t_llama_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
     "p2t_llama_hidden_forward": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, vp, i32, i32, i32, vp, vp,
                                        sz, vp]),
+    "p2t_llama_hidden_forward_embeds": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, vp, i32, i32, i32, vp, vp,
+                                              sz, vp]),
+    "p2t_llama_embed_tokens": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, i64, vp, vp]),
+    "p2t_positions_where": (i32, [vp, i64, i32, i64, vp, vp, vp]),
+    "p2t_scatter_rows": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, i64, i32, vp]),
+    "p2t_cross_entropy_shifted": (i32, [vp, i64, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp]),
     "p2t_adapter_forward": (i32, [C.POINTER(AdapterConfigC), C.POINTER(AdapterWeightsC), vp, i64, i64, vp,
                                   C.POINTER(AdapterSavedC), vp]),
     "p2t_adapter_backward_workspace_bytes": (sz, [C.POINTER(AdapterConfigC), i64]),

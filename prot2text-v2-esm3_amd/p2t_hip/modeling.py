@@ -440,18 +440,49 @@ class LlamaTextModel(nn.Module):
             attention_mask = torch.ones_like(input_ids)
         if tuple(attention_mask.shape) != (B, T):
             raise ValueError(f"attention_mask shape {tuple(attention_mask.shape)} != input ids {(B, T)}")
+        dev = self.embed_tokens.weight.device
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        return self._run(ids, None, attention_mask, B, T, k)
+
+    def _run(self, ids, embeds, attention_mask, B, T, k):
         e = self._engine
         if e is None or e["n"] < k:
             e = self._build_engine(k)
         dev = self.embed_tokens.weight.device
-        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         nbytes = call("p2t_llama_workspace_bytes", C.byref(e["cfg"]), B, T)
         ws = self._ws.get((B, T, torch.cuda.current_stream().cuda_stream), nbytes, dev)
         out = torch.empty((B, T, self.spec.hidden_size), dtype=torch.float32, device=dev)
-        call("p2t_llama_hidden_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, int(k), ptr(out),
-             ptr(ws), ws.numel(), stream())
+        if embeds is None:
+            call("p2t_llama_hidden_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, int(k), ptr(out),
+                 ptr(ws), ws.numel(), stream())
+        else:
+            call("p2t_llama_hidden_forward_embeds", C.byref(e["cfg"]), C.byref(e["w"]), ptr(embeds), ptr(mask), B, T, int(k),
+                 ptr(out), ptr(ws), ws.numel(), stream())
         return out
+
+    def embed(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """`get_input_embeddings()(input_ids)` as the f32 residual-stream input [B, T, hidden]."""
+        if input_ids is None or input_ids.dim() != 2:
+            raise ValueError("input_ids must be a [batch, seq_len] tensor of token ids")
+        e = self._engine or self._build_engine(0)
+        dev = self.embed_tokens.weight.device
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty((*ids.shape, self.spec.hidden_size), dtype=torch.float32, device=dev)
+        call("p2t_llama_embed_tokens", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ids.numel(), ptr(out), stream())
+        return out
+
+    def hidden_state_from_embeds(self, inputs_embeds: torch.Tensor, attention_mask, k: int) -> torch.Tensor:
+        """hidden_states[k] from caller-supplied layer-0 inputs (f32 [B, T, hidden])."""
+        if inputs_embeds is None or inputs_embeds.dim() != 3 or inputs_embeds.shape[2] != self.spec.hidden_size:
+            raise ValueError(f"inputs_embeds must be [batch, seq_len, {self.spec.hidden_size}]")
+        B, T, _ = inputs_embeds.shape
+        if attention_mask is None:
+            attention_mask = torch.ones((B, T), dtype=torch.int64, device=inputs_embeds.device)
+        if tuple(attention_mask.shape) != (B, T):
+            raise ValueError(f"attention_mask shape {tuple(attention_mask.shape)} != inputs {(B, T)}")
+        emb = inputs_embeds.to(device=self.embed_tokens.weight.device, dtype=torch.float32).contiguous()
+        return self._run(None, emb, attention_mask, B, T, k)
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
@@ -461,6 +492,22 @@ class LlamaTextModel(nn.Module):
         if output_attentions:
             raise NotImplementedError("output_attentions is not available from the fused decoder")
         return LlamaTextOutput(LazyHiddenStates(self, input_ids, attention_mask))
+
+
+class CausalLMOutput:
+    """The fields of HF `CausalLMOutputWithPast` this path fills; indexable like a ModelOutput ((loss,) logits)."""
+
+    def __init__(self, loss, logits):
+        self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions = loss, logits, None, None, None
+
+    def to_tuple(self):
+        return tuple(v for v in (self.loss, self.logits) if v is not None)
+
+    def __getitem__(self, i):
+        return getattr(self, i) if isinstance(i, str) else self.to_tuple()[i]
+
+    def __iter__(self):
+        return iter(self.to_tuple())
 
 
 class LlamaDecoder(nn.Module):
@@ -486,10 +533,41 @@ class LlamaDecoder(nn.Module):
     def get_input_embeddings(self):
         return self.model.embed_tokens
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("LlamaForCausalLM.forward (LM head + cross-entropy) is the SFT stage "
-                                  "(scripts/train_instruct.py), out of scope for the contrastive path; use "
-                                  "llama_decoder.model(...).hidden_states[k]")
+    def _lm_head_padded(self) -> torch.Tensor:
+        w = self.lm_head.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_lm_key", None) != key:
+            self._lm_w, self._lm_key = _pad_cols(w.detach(), round_up(self.spec.hidden_size, 64), w.dtype), key
+        return self._lm_w
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                cache_position=None, **kwargs):
+        """LlamaForCausalLM.forward without a KV cache: all layers -> final RMSNorm -> LM head -> (shifted cross-entropy).
+        Restates transformers/models/llama/modeling_llama.py (LlamaForCausalLM.forward) and loss_utils.ForCausalLMLoss.
+        Forward only: the LM loss carries no autograd graph (LoRA training of the decoder is out of scope)."""
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if position_ids is not None or past_key_values is not None or use_cache or cache_position is not None:
+            raise NotImplementedError("position_ids / KV cache / cache_position belong to generation, which is out of scope")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not available from the fused decoder")
+        s, m = self.spec, self.model
+        if s.hidden_size % 64:
+            raise ValueError("the LM head path needs hidden_size % 64 == 0")
+        L = s.num_hidden_layers
+        h = m.hidden_state(input_ids, attention_mask, L) if inputs_embeds is None else m.hidden_state_from_embeds(inputs_embeds, attention_mask, L)
+        B, T, H = h.shape
+        dt = m.dtype
+        a = h.view(B * T, H) if dt == torch.float32 else ops.cast(h.view(B * T, H), dt)      # post-norm states in model dtype
+        logits = ops.gemm_nt(a, self._lm_head_padded(), None, n=s.vocab_size, k=H, out_dtype=dt)   # [B*T, ld(V)]
+        logits = logits.view(B, T, -1)
+        loss = None
+        if labels is not None:
+            if tuple(labels.shape) != (B, T):
+                raise ValueError(f"labels shape {tuple(labels.shape)} != {(B, T)}")
+            loss = ops.cross_entropy_shifted(logits, labels.to(logits.device), s.vocab_size)[0][0]
+        return CausalLMOutput(loss=loss, logits=logits[..., : s.vocab_size])
 
     def generate(self, *args, **kwargs):
         raise NotImplementedError("generation is out of scope for the contrastive path")
@@ -544,9 +622,36 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
         self.llama_decoder.model.invalidate_engine()
         return self
 
-    def prepare_decoder_inputs(self, *args, **kwargs):
-        raise NotImplementedError("placeholder replacement feeds the SFT / generation stages "
-                                  "(reference :108-139), out of scope for the contrastive path")
+    def prepare_decoder_inputs(self, input_ids, encoder_hidden_states, attention_mask=None, encoder_attention_mask=None):
+        """Embed `input_ids` and replace the placeholder positions by the encoder (adapter) states, in row-major order on
+        both sides -- `inputs_embeds[input_ids == placeholder_id] = encoder_hidden_states[encoder_attention_mask.bool()]`
+        (reference :108-139).  Returns (inputs_embeds f32 [B, T, H], attention_mask)."""
+        if input_ids is None or input_ids.dim() != 2:
+            raise ValueError("input_ids must be passed to locate the placeholders")
+        B, T = input_ids.shape
+        dev = self.llama_decoder.model.embed_tokens.weight.device
+        enc = encoder_hidden_states
+        if enc.dim() != 3 or enc.shape[0] != B:
+            raise ValueError(f"encoder_hidden_states must be [batch={B}, encoder_seq_len, hidden]")
+        H = self.llama_decoder.spec.hidden_size
+        if enc.shape[2] != H:
+            raise ValueError(f"encoder states have {enc.shape[2]} features, the decoder embeds {H}")
+        if attention_mask is None:
+            attention_mask = torch.ones((B, T), dtype=torch.long, device=dev)
+        if encoder_attention_mask is None:
+            encoder_attention_mask = torch.ones(enc.shape[:2], dtype=torch.long, device=dev)
+        ids = input_ids.to(dev)
+        embeds = self.llama_decoder.model.embed(ids)
+        dst_pos, n_dst = ops.positions_where(ids, int(self.config.placeholder_id))
+        src_pos, n_src = ops.positions_where(encoder_attention_mask.to(dev))
+        src = enc.reshape(B * enc.shape[1], H)
+        if src.dtype not in (torch.float32, torch.bfloat16) or src.stride(1) != 1:
+            src = src.float().contiguous()
+        ops.scatter_rows(embeds.view(B * T, H), dst_pos, n_dst, src, src_pos, n_src, H)
+        nd, ns = int(n_dst.item()), int(n_src.item())          # torch's boolean-mask assignment raises on a count mismatch
+        if nd != ns:
+            raise RuntimeError(f"shape mismatch: {ns} encoder states cannot be assigned to {nd} placeholder positions")
+        return embeds, attention_mask
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, labels=None,
                 protein_input_ids=None, protein_attention_mask=None, protein_position_ids=None, protein_head_mask=None,
@@ -566,8 +671,15 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
         adapter_output = self.adapter.forward_padded(enc.view(B * T, Hp)).reshape(B, T, -1)   # reference :191
         if return_adapter_outputs:                 # reference :192-193
             return adapter_output, protein_attention_mask
-        raise NotImplementedError("the decoder half of forward (placeholder scatter + Llama LM loss, reference :195-215) "
-                                  "is the SFT stage and out of scope; use return_encoder_outputs / return_adapter_outputs")
+        inputs_embeds, attention_mask = self.prepare_decoder_inputs(input_ids=input_ids, encoder_hidden_states=adapter_output,
+                                                                    attention_mask=attention_mask,
+                                                                    encoder_attention_mask=protein_attention_mask)   # :195-201
+        if return_decoder_inputs:                  # :202-203
+            return inputs_embeds, attention_mask
+        return self.llama_decoder.forward(input_ids=None, attention_mask=attention_mask, position_ids=position_ids,
+                                          past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,
+                                          use_cache=use_cache, output_attentions=output_attentions, return_dict=return_dict,
+                                          cache_position=cache_position)                                              # :204-215
 
     def generate(self, *args, **kwargs):
         raise NotImplementedError("generation is out of scope for the contrastive path")

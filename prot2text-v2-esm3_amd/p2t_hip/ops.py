@@ -93,6 +93,39 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
     return out
 
 
+def positions_where(values: torch.Tensor, match: int | None = None):
+    """Flat positions (int32, array order) of `values == match` (or `values != 0` when match is None) and their count
+    (int32 [1]), both on the device: the enumeration order of torch's boolean-mask indexing."""
+    v = values.to(torch.int64).contiguous().view(-1)
+    pos = torch.empty((v.numel(),), dtype=torch.int32, device=v.device)
+    count = torch.empty((1,), dtype=torch.int32, device=v.device)
+    call("p2t_positions_where", ptr(v), v.numel(), 0 if match is not None else 1, int(match or 0), ptr(pos), ptr(count), stream())
+    return pos, count
+
+
+def scatter_rows(dst: torch.Tensor, dst_pos, n_dst, src: torch.Tensor, src_pos, n_src, H: int) -> None:
+    """dst[dst_pos[r], :H] = src[src_pos[r], :H] for r < min(n_dst, n_src); dst f32 2-D, src bf16 / f32 2-D."""
+    _chk(dst.dim() == 2 and src.dim() == 2 and dst.dtype == torch.float32 and dst.stride(1) == 1 and src.stride(1) == 1,
+         "scatter_rows: 2-D row-major operands, f32 destination")
+    call("p2t_scatter_rows", ptr(dst), dst.stride(0), ptr(dst_pos), ptr(src), src.stride(0), dt_of(src), ptr(src_pos), ptr(n_dst),
+         ptr(n_src), min(dst_pos.numel(), src_pos.numel()), int(H), stream())
+
+
+def cross_entropy_shifted(logits: torch.Tensor, labels: torch.Tensor, V: int, ignore_index: int = -100):
+    """HF causal-LM loss: logits [B, T, ld >= V], labels [B, T] -> (loss f32 [1], n_targets int32 [1])."""
+    _chk(logits.dim() == 3 and labels.dim() == 2 and tuple(logits.shape[:2]) == tuple(labels.shape) and logits.stride(2) == 1
+         and logits.is_contiguous(), "cross_entropy_shifted: logits [B, T, ld] contiguous, labels [B, T]")
+    B, T, ld = logits.shape
+    lab = labels.to(torch.int64).contiguous()
+    row_loss = torch.empty((B * T,), dtype=torch.float32, device=logits.device)
+    row_valid = torch.empty((B * T,), dtype=torch.int32, device=logits.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    count = torch.empty((1,), dtype=torch.int32, device=logits.device)
+    call("p2t_cross_entropy_shifted", ptr(logits), ld, dt_of(logits), ptr(lab), B, T, int(V), int(ignore_index), ptr(row_loss),
+         ptr(row_valid), ptr(loss), ptr(count), stream())
+    return loss, count
+
+
 def gemm_fix_workspace(device) -> torch.Tensor:
     """Zeroed split-K fix-up workspace for gemm_nt(fix_ws=..., fix_epoch=1, 2, ...)."""
     return torch.zeros((call("p2t_gemm_fix_workspace_bytes"),), dtype=torch.uint8, device=device)

@@ -347,9 +347,61 @@ def run_train_state(ref):
     print("wrote train_state.json / train_state_model.pt / train_state_optimizer_scheduler.pt", out)
 
 
+
+def sft_batch(B, lens, T_prompt, T_desc, placeholder_id, pad_id, id_high, seed):
+    """Deterministic SFT-style batch: left-padded prompts holding len+2 placeholders, right-padded descriptions."""
+    rng = np.random.default_rng(seed)
+    T_p = max(lens) + 2
+    pid, pmask = synth.protein_batch(seed, B, T_p, [n + 2 for n in lens])
+    ids = np.full((B, T_prompt + T_desc), pad_id, dtype=np.int64)
+    mask = np.zeros((B, T_prompt + T_desc), dtype=np.int64)
+    labels = np.full((B, T_prompt + T_desc), -100, dtype=np.int64)
+    for b, n in enumerate(lens):
+        head = rng.integers(0, id_high, size=3)
+        prompt = np.concatenate([head[:2], np.full(n + 2, placeholder_id), head[2:]])
+        ids[b, T_prompt - len(prompt):T_prompt] = prompt
+        mask[b, T_prompt - len(prompt):T_prompt] = 1
+        nd = int(rng.integers(2, T_desc + 1))
+        desc = rng.integers(0, id_high, size=nd)
+        ids[b, T_prompt:T_prompt + nd] = desc
+        mask[b, T_prompt:T_prompt + nd] = 1
+        labels[b, T_prompt:T_prompt + nd] = desc
+    return pid, pmask, ids, mask, labels
+
+
+def run_sft(ref):
+    """Full forward of the reference class with labels (models/modeling_esm2llama_instruct.py:141-215): decoder inputs
+    after the placeholder scatter, logits and the LM loss of HF LlamaForCausalLM, tiny towers."""
+    esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+    llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,
+                            num_key_value_heads=2, vocab_size=512)
+    ad = specs.AdapterSpec(64, 96, 64, 0.3)
+    model = build_reference_model(ref, esm, llama, ad, 0)
+    placeholder_id = 511
+    model.config.placeholder_id = placeholder_id
+    lens = [10, 6, 3]
+    pid, pmask, ids, mask, labels = sft_batch(3, lens, 18, 9, placeholder_id, 510, 500, 7)
+    t = lambda a: torch.from_numpy(a)
+    with torch.no_grad():
+        emb, m2 = model(input_ids=t(ids), attention_mask=t(mask), protein_input_ids=t(pid), protein_attention_mask=t(pmask),
+                        return_decoder_inputs=True)
+        out = model(input_ids=t(ids), attention_mask=t(mask), labels=t(labels), protein_input_ids=t(pid),
+                    protein_attention_mask=t(pmask))
+        out_nolabel = model(input_ids=t(ids), attention_mask=t(mask), protein_input_ids=t(pid), protein_attention_mask=t(pmask))
+    assert torch.equal(m2, t(mask)) and out_nolabel.loss is None
+    meta = dict(esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad), placeholder_id=placeholder_id,
+                lens=lens)
+    import json
+    path = os.path.join(HERE, "sft_tiny.npz")
+    np.savez_compressed(path, protein_input_ids=pid, protein_attention_mask=pmask, input_ids=ids, attention_mask=mask, labels=labels,
+                        inputs_embeds=emb.numpy(), logits=out.logits.numpy(), loss=np.float32(out.loss.item()),
+                        meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print(f"wrote {path}: loss {float(out.loss):.6f}, logits {tuple(out.logits.shape)}")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,cfg1,collate,train_state")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,cfg1,collate,train_state,sft")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -361,6 +413,8 @@ def main():
         run_collate(ref)
     if "train_state" in only:
         run_train_state(ref)
+    if "sft" in only:
+        run_sft(ref)
     if "tiny" in only:
         esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
         llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,
