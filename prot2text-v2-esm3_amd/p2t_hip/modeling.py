@@ -12,9 +12,10 @@ models/modeling_esm2llama_instruct.py:45-268, with the arithmetic delegated to l
 
 The modules below are PARAMETER CONTAINERS with HuggingFace key names (so reference checkpoints
 load with load_state_dict) plus an "engine": packed GEMM-layout copies of the weights and the C
-structs that point at them.  No torch op computes anything on this path.  Everything after the
-adapter exit (placeholder scatter, LM head, generate) belongs to the SFT / generation stages and
-is out of scope for this path: those entry points raise NotImplementedError.
+structs that point at them.  No torch op computes anything on this path.  After the adapter exit the
+forward continues as upstream (placeholder scatter -> full decoder -> LM head -> shifted cross-entropy,
+SURVEY.md section 8f row 3) as a forward-only path; generation and the decoder backward are out of
+scope and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -331,8 +332,8 @@ class LazyHiddenStates:
     """`outputs.hidden_states` of the text tower: indexing [k] runs the decoder up to layer k only
     (the reference materialises all L+1 states and reads index 16, train_contrast.py:294-304)."""
 
-    def __init__(self, model: "LlamaTextModel", ids, mask):
-        self._m, self._ids, self._mask, self._cache = model, ids, mask, {}
+    def __init__(self, model: "LlamaTextModel", ids, mask, embeds=None):
+        self._m, self._ids, self._mask, self._embeds, self._cache = model, ids, mask, embeds, {}
 
     def __len__(self):
         return self._m.spec.num_hidden_layers + 1
@@ -345,7 +346,8 @@ class LazyHiddenStates:
         if not 0 <= k < len(self):
             raise IndexError(f"hidden_states index {k} out of range for {len(self) - 1} layers")
         if k not in self._cache:
-            self._cache[k] = self._m.hidden_state(self._ids, self._mask, k)
+            self._cache[k] = (self._m.hidden_state(self._ids, self._mask, k) if self._embeds is None
+                              else self._m.hidden_state_from_embeds(self._embeds, self._mask, k))
         return self._cache[k]
 
     def __iter__(self):
@@ -486,12 +488,13 @@ class LlamaTextModel(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
-        if inputs_embeds is not None or position_ids is not None or past_key_values is not None or use_cache:
-            raise NotImplementedError("inputs_embeds / position_ids / KV cache belong to the SFT and generation stages, "
-                                      "which are out of scope of the contrastive path")
+        if position_ids is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("position_ids / KV cache belong to generation, which is out of scope")
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         if output_attentions:
             raise NotImplementedError("output_attentions is not available from the fused decoder")
-        return LlamaTextOutput(LazyHiddenStates(self, input_ids, attention_mask))
+        return LlamaTextOutput(LazyHiddenStates(self, input_ids, attention_mask, inputs_embeds))
 
 
 class CausalLMOutput:
@@ -512,7 +515,7 @@ class CausalLMOutput:
 
 class LlamaDecoder(nn.Module):
     """Stands where the reference puts HF `LlamaForCausalLM` (attribute `llama_decoder`): owns
-    `.model` (text tower) and `.lm_head`.  The causal-LM forward / generate are SFT-stage features."""
+    `.model` (text tower) and `.lm_head`; `forward` is the cache-less causal-LM forward (logits + optional loss)."""
 
     def __init__(self, config, dtype=torch.float32, device="cuda"):
         super().__init__()
