@@ -205,8 +205,12 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         model(protein_input_ids=ids, protein_attention_mask=torch.ones((2, 7), dtype=torch.int64, device=dev()),
               return_adapter_outputs=True)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="shape mismatch"):      # no placeholder in input_ids (torch's boolean-mask assignment error)
         model(input_ids=ids, protein_input_ids=ids, protein_attention_mask=torch.ones_like(ids))
+    with pytest.raises(NotImplementedError):
+        model.generate(ids)
+    with pytest.raises(NotImplementedError):
+        model(input_ids=ids, protein_input_ids=ids, protein_attention_mask=torch.ones_like(ids), protein_head_mask=torch.ones(1))
     with pytest.raises(IndexError):
         model.llama_decoder.model(input_ids=ids, attention_mask=torch.ones_like(ids), output_hidden_states=True).hidden_states[5]
     with pytest.raises(ValueError):
