@@ -235,6 +235,14 @@ def main():
             out["config"]["batch64_check"] = {"samples_per_s": round(64 / dt64, 2), "ms_per_step": round(dt64 * 1e3, 2),
                                               "step_tflops": round(tf64, 1), "frac_of_bf16_peak": round(tf64 / PEAK_BF16_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
+            # forward + loss only (eval mode): the quantity the CPU baseline below measures
+            trainer.evaluate(batch)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                trainer.evaluate(batch)
+            torch.cuda.synchronize()
+            out["config"]["forward_only_samples_per_s"] = round(B * 3 / (time.perf_counter() - t2), 2)
             out["cpu_baseline"] = cpu_baseline(model, esm, llama, args.config, Tp, Tt, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -292,9 +292,9 @@ class ContrastiveTrainer:
         hs = self.model.llama_decoder.model.hidden_state(tid, tmask, self.layer)
         return ops.l2norm_rows(ops.readout(hs, tmask, self.readout_fn))
 
-    def forward_backward(self, batch: Dict[str, torch.Tensor], accumulate: bool = False) -> torch.Tensor:
+    def forward_backward(self, batch: Dict[str, torch.Tensor], accumulate: bool = False, backward: bool = True) -> torch.Tensor:
         """Loss (device scalar, f32 [1]) and adapter gradients into self.g (summed over segments,
-        all-reduce-averaged over ranks).  No host synchronisation."""
+        all-reduce-averaged over ranks).  No host synchronisation.  backward=False stops after the loss."""
         m, c = self.model, self.c
         pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
         tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
@@ -352,6 +352,8 @@ class ContrastiveTrainer:
             labels = torch.arange(sl.start + offset, sl.stop + offset, device=self.dev, dtype=torch.int32)
             _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, 1.0 / nseg, self.loss,
                                             accumulate=(s > 0 or accumulate))
+            if not backward:
+                continue
             dp = ops.infonce_backward(t_all, labels, logits, self.temperature, 1.0 / nseg)
             dpooled = ops.l2norm_rows_backward(pooled, dp)
             call("p2t_readout_backward", ptr(y3), ops.dt_of(y3), y3.stride(1), ptr(rmask.to(torch.int64).contiguous()) if rmask is not None else None,
@@ -359,7 +361,7 @@ class ContrastiveTrainer:
             call("p2t_adapter_backward", C.byref(cfg), C.byref(wts), ptr(enc), Hp, M, C.byref(b["saved"]), ptr(b["dY"]),
                  ptr(self.g[0]), ptr(self.g[1]), ptr(self.g[2]), ptr(self.g[3]), int(s > 0 or accumulate), ptr(b["ws"]),
                  b["ws"].numel(), stream())
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if backward and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG if self.flat_g.is_cuda else dist.ReduceOp.SUM, group=self.group)
             if not self.flat_g.is_cuda:
                 self.flat_g /= dist.get_world_size(self.group)
@@ -388,9 +390,7 @@ class ContrastiveTrainer:
         saved = self.train_mode
         self.train_mode = False
         try:
-            g = self.flat_g.clone()
-            loss = self.forward_backward(batch).clone()
-            self.flat_g.copy_(g)
+            loss = self.forward_backward(batch, backward=False).clone()
         finally:
             self.train_mode = saved
         return loss

@@ -92,6 +92,9 @@ def test_fp32_adapter_gradients_autograd_and_trainer(golden, case):
         assert abs(float(to_np(loss2)[0]) - float(g[f"loss_seg{nseg}_mix_L{k}"])) < LOSS_TOL
         for t, n in zip(tr.g, names):
             assert rel(to_np(t), g[f"grad_seg{nseg}_{n}"]) < 5e-4, (nseg, n)
+        g_before = tr.flat_g.clone()
+        loss3 = tr.evaluate(b)                                   # forward-only: same loss, gradients untouched
+        assert float(to_np(loss3)[0]) == float(to_np(loss2)[0]) and torch.equal(tr.flat_g, g_before)
         if nseg == 1:
             gn = tr.optimizer_step()
             assert abs(float(to_np(gn)[0]) - float(g["opt_gradnorm"])) < 1e-3 * float(g["opt_gradnorm"])
