@@ -554,11 +554,12 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
         const int ns = K >> 5;
         // measured (profiles/r01_microbench_v4.log): whole rounds -> persistent (+5..13 %); a partial last round with
         // K >= 4096 -> persistent + split-K fix-up (+2..4 % over the per-tile kernel with the fix-up); K < 4096 -> plain
-        // persistent if there are at least four rounds (QKV: +13 %), else the per-tile kernel (o-proj, 2.5 rounds: the
-        // read-modify-write epilogue gains nothing from persistence and the idle half round costs more)
+        // persistent if there are at least four rounds (QKV: +13 %) or the epilogue is a read-modify-write of the residual
+        // stream (o-proj, 2.5 rounds: with the stream cold in HBM, as it is inside a step, the undrained stores win
+        // 0.4 % of the step; with it hot in the Infinity Cache, as in the micro-benchmark, the per-tile kernel is 6 % ahead)
         const int64_t rem = items % kCUs;
         const bool eligible = items >= kCUs && (ns & 3) == 0 && ns >= 12 && M % 256 == 0 && N % 256 == 0 && n_cover == N;
-        const bool pick = tile == 3 || tile == 4 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs));
+        const bool pick = tile == 3 || tile == 4 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
         if (eligible && pick) {
             int64_t n_full = items, n_tail = 0;
             SplitFix fix{};
