@@ -1,0 +1,130 @@
+"""Parity at BASELINE.json's own model sizes.
+
+* configs[1] (esm2_t12_35M + Llama-3.2-1B, bf16): the HIP path against the CPU oracle on the FULL models (12 + 16
+  layers, head_dim 24 encoder, 128256-token vocabulary), a 4-pair ragged slice of the batch so the oracle finishes in
+  seconds; both sides read the same weights (the GPU model's).
+* configs[2] (esm2_t36_3B + Llama-3.1-8B, bf16, 1024 residues): too large for the oracle, so size-independent properties
+  of the step: permutation equivariance, padding invariance, segment additivity, agreement of the bf16 MFMA pipeline with
+  the exact fp32 pipeline on the same weights, and a falling loss under the fused optimizer step.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import build_model, dev, rel, to_dev, to_np
+from p2t_hip import specs, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch(pid, pmask, tid, tmask):
+    return dict(protein_input_ids=to_dev(pid), protein_attention_mask=to_dev(pmask),
+                description_input_ids=to_dev(tid), description_attention_mask=to_dev(tmask))
+
+
+def _embeddings(P, model, b, layer=16):
+    with torch.no_grad():
+        p = P.l2_normalize(P.get_sequence_embeddings(model, b["protein_input_ids"], b["protein_attention_mask"]))
+        t = P.l2_normalize(P.get_description_embeddings(model, b["description_input_ids"], b["description_attention_mask"], layer))
+    return to_np(p), to_np(t)
+
+
+def test_cfg2_full_models_vs_cpu_oracle():
+    import p2t_hip as P
+    from oracle import p2t_oracle as O
+    sys.path.insert(0, ROOT)
+    from bench import GpuWeights
+    esm_name, llama_name, _, _, Tp, Tt = specs.CONFIGS["cfg2"]
+    esm, llama = specs.esm_spec(esm_name), specs.llama_spec(llama_name)
+    ad = specs.adapter_spec(esm, llama)
+    model = build_model(esm, llama, ad, torch.bfloat16, 0).eval()
+    B = 4
+    pid, pmask = synth.protein_batch(21, B, Tp, [Tp, 300, 131, 40])
+    tid, tmask = synth.text_batch(21, B, Tt, 128000, [Tt, 77, 30, 18], 128002, 128009)
+    b = _batch(pid, pmask, tid, tmask)
+    layer = min(16, llama.num_hidden_layers)
+    with torch.no_grad():
+        p = P.l2_normalize(P.get_sequence_embeddings(model, b["protein_input_ids"], b["protein_attention_mask"]))
+        t = P.l2_normalize(P.get_description_embeddings(model, b["description_input_ids"], b["description_attention_mask"], layer))
+        loss = float(P.BatchInfoNCELoss()(p, t))
+    ref = O.contrastive_step(esm, llama, GpuWeights(model), pid, pmask, tid, tmask, layer=layer, num_segments=1, prec=O.BF16)
+    assert rel(to_np(t), ref["text"]) < 2e-2
+    assert rel(to_np(p), ref["protein"]) < 2e-2
+    assert abs(loss - float(ref["loss"])) < 2e-2 * max(1.0, abs(float(ref["loss"])))
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    import p2t_hip as P
+    esm_name, llama_name, _, _, Tp, Tt = specs.CONFIGS["cfg3"]
+    esm, llama = specs.esm_spec(esm_name), specs.llama_spec(llama_name)
+    ad = specs.adapter_spec(esm, llama)
+    model = build_model(esm, llama, ad, torch.bfloat16, 0).eval()
+    B = 4
+    lens_p, lens_t = [600, 411, 250, 37], [100, 64, 33, 9]
+    pid, pmask = synth.protein_batch(31, B, Tp, lens_p)
+    tid, tmask = synth.text_batch(31, B, Tt, 128000, lens_t, 128002, 128009)
+    yield dict(P=P, model=model, esm=esm, llama=llama, ad=ad, Tp=Tp, Tt=Tt, pid=pid, pmask=pmask, tid=tid, tmask=tmask)
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_permutation_equivariance_and_padding_invariance(cfg3):
+    P, model = cfg3["P"], cfg3["model"]
+    pid, pmask, tid, tmask = cfg3["pid"], cfg3["pmask"], cfg3["tid"], cfg3["tmask"]
+    mix = lambda b: (to_np(P.l2_normalize(P.readout_embeddings(
+        model(protein_input_ids=b["protein_input_ids"], protein_attention_mask=b["protein_attention_mask"], return_adapter_outputs=True)[0],
+        b["protein_attention_mask"], "mix"))),
+        to_np(P.l2_normalize(P.get_description_embeddings(model, b["description_input_ids"], b["description_attention_mask"], 16))))
+    with torch.no_grad():
+        p0, t0 = mix(_batch(pid, pmask, tid, tmask))
+        perm = [2, 0, 3, 1]
+        p1, t1 = mix(_batch(pid[perm], pmask[perm], tid[perm], tmask[perm]))
+        assert rel(p1, p0[perm]) < 1e-3 and rel(t1, t0[perm]) < 1e-3           # rows do not see each other
+        # every sequence fits in 640 residues / 104 tokens: dropping the all-padding tail changes nothing
+        p2, t2 = mix(_batch(pid[:, :640], pmask[:, :640], tid[:, :104], tmask[:, :104]))
+        assert rel(p2, p0) < 1e-3 and rel(t2, t0) < 1e-3
+    assert np.isfinite(p0).all() and np.isfinite(t0).all()
+    assert np.allclose(np.linalg.norm(p0, axis=1), 1.0, atol=1e-3)
+
+
+def test_cfg3_segments_and_fused_trainer(cfg3):
+    P, model = cfg3["P"], cfg3["model"]
+    b = _batch(cfg3["pid"], cfg3["pmask"], cfg3["tid"], cfg3["tmask"])
+    model.train()
+    model.adapter.dropout.p = 0.0
+    losses = {}
+    grads = {}
+    for nseg in (1, 2, 4):
+        tr = P.ContrastiveTrainer(model, num_segments=nseg, train_mode=False, lr=1e-3)
+        losses[nseg] = float(to_np(tr.forward_backward(b))[0])
+        grads[nseg] = to_np(tr.flat_g).copy()
+    # the segmented loss is the mean of per-segment means of equally sized segments = the batch mean; gradients add up
+    assert abs(losses[2] - losses[1]) < 1e-4 * max(1.0, abs(losses[1])) and abs(losses[4] - losses[1]) < 1e-4 * max(1.0, abs(losses[1]))
+    assert rel(grads[2], grads[1]) < 2e-2 and rel(grads[4], grads[1]) < 2e-2
+    assert 0.0 < losses[1] < 2.0 * np.log(4) + 1.0
+    # reference hyper-parameters (lr 2e-4): ten times that collapses a feature of a sequence to a constant after one step
+    # and the eps-free std readout then back-propagates 0/0, exactly as the reference's would
+    tr = P.ContrastiveTrainer(model, num_segments=1, train_mode=False, lr=2e-4)
+    first = float(to_np(tr.step(b))[0])
+    for _ in range(5):
+        last = float(to_np(tr.step(b))[0])
+    assert np.isfinite(last) and last < 0.6 * first                             # the fused step optimises the loss it reports
+    model.eval()
+
+
+def test_cfg3_bf16_pipeline_vs_exact_fp32_pipeline(cfg3):
+    """Same synthetic weights (fp32 masters -> the bf16 model holds their roundings), two pairs, full depth."""
+    P = cfg3["P"]
+    m32 = build_model(cfg3["esm"], cfg3["llama"], cfg3["ad"], torch.float32, 0).eval()
+    b = _batch(cfg3["pid"][:2], cfg3["pmask"][:2], cfg3["tid"][:2], cfg3["tmask"][:2])
+    p16, t16 = _embeddings(P, cfg3["model"], b)
+    p32, t32 = _embeddings(P, m32, b)
+    del m32
+    torch.cuda.empty_cache()
+    assert rel(t16, t32) < 3e-2
+    assert rel(p16, p32) < 5e-2                                                  # 36 layers of bf16 storage
