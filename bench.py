@@ -234,6 +234,19 @@ def main():
             tf64 = f["total"] * 64 / dt64 / 1e12
             out["config"]["batch64_check"] = {"samples_per_s": round(64 / dt64, 2), "ms_per_step": round(dt64 * 1e3, 2),
                                               "step_tflops": round(tf64, 1), "frac_of_bf16_peak": round(tf64 / PEAK_BF16_TFLOPS, 4)}
+        if world == 1 and not args.no_batch64_check and not args.overlap:
+            # the two towers on two HIP streams (ContrastiveTrainer(overlap_streams=True), `--overlap`): co-scheduled kernels
+            # fill each other's partial rounds.  Not the default because per-kernel durations (roofline, rocprof) then
+            # include the co-runner; measured here after and outside the timed region, same batch.
+            trainer.overlap_streams = True
+            trainer.step(batch)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(3):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            out["config"]["two_stream_check"] = {"samples_per_s": round(B * 3 / (time.perf_counter() - t3), 2)}
+            trainer.overlap_streams = False
         if world == 1 and not args.no_cpu_baseline:
             # forward + loss only (eval mode): the quantity the CPU baseline below measures
             trainer.evaluate(batch)
