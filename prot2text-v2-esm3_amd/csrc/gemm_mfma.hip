@@ -356,13 +356,14 @@ __global__ void __launch_bounds__(512)
     //   W'0 G0 W'1 X'0 G1 W'2 X'1 G2 W'3 X'2 G3 X'3 X'4 X'5 X'6 -- X'7   (' = of stage s+1, G = DMA piece of stage s+3)
     // X'j follows the last MFMA of fragment j (X'7 trails the last pair; it is not needed before pair 14 of step s+1).
     // WAITK: 3 = steady state (one stage may stay in flight; plus the previous epilogue's operations when `ext`), 0..2 =
-    // that many stages, 4 / 5 = the last two steps of a tile.  LOADF: read the fragments of stage s+1 (slot fslot).  ISSUE (compile time) and
+    // that many stages, 4 / 5 = the last two steps of a tile, 6 = 3 for the first step of a tile (C operand = 0).  LOADF: read the fragments of stage s+1 (slot fslot).  ISSUE (compile time) and
     // `more` (run time): start the DMA of stage s+3 into slot islot at element offset koff of the issue pointers.
     auto step = [&](auto waitk, auto loadf, auto issue, bool ext, bool more, int fslot, int islot, int koff, const bf16x8 (&wc)[NT],
                     bf16x8 (&wnx)[NT]) {
         constexpr int WAITK = decltype(waitk)::value;
         constexpr bool LOADF = decltype(loadf)::value, ISSUE = decltype(issue)::value;
-        if constexpr (WAITK == 3) {
+        constexpr bool FIRST = WAITK == 6;              // first step of a tile: the accumulators start from the inline constant 0
+        if constexpr (WAITK == 3 || WAITK == 6) {
             if (ext) __builtin_amdgcn_s_waitcnt(vm_imm(kExtCount));
             else __builtin_amdgcn_s_waitcnt(vm_imm(NL));
         } else if constexpr (WAITK == 4) {              // second to last step of a tile: steady-state wait, or drain
@@ -380,10 +381,11 @@ __global__ void __launch_bounds__(512)
         auto rw = [&](int i) { if constexpr (LOADF) wnx[i] = *reinterpret_cast<const bf16x8*>(ws + i * 1024); };
         auto rx = [&](int j) { if constexpr (LOADF) x[j] = *reinterpret_cast<const bf16x8*>(xs + j * 1024); };
         auto g = [&](auto which) { if constexpr (ISSUE) { if (more) dma(which, islot, koff); } };
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         auto pair = [&](int p) {
             const int j = p >> 1, i0 = (p & 1) * 2;
-            acc[i0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0], x[j], acc[i0][j], 0, 0, 0);
-            acc[i0 + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0 + 1], x[j], acc[i0 + 1][j], 0, 0, 0);
+            acc[i0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0], x[j], FIRST ? zero4 : acc[i0][j], 0, 0, 0);
+            acc[i0 + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0 + 1], x[j], FIRST ? zero4 : acc[i0 + 1][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         rw(0); pair(0);
@@ -408,6 +410,7 @@ __global__ void __launch_bounds__(512)
     using I3 = std::integral_constant<int, 3>;
     using I4 = std::integral_constant<int, 4>;
     using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
     using T = std::true_type;
     using F = std::false_type;
 
@@ -430,12 +433,8 @@ __global__ void __launch_bounds__(512)
         for (int j = 0; j < MT; ++j) x[j] = *reinterpret_cast<const bf16x8*>(smem + x_off + j * 1024);
         const int nxt = item + (int)gridDim.x;
         const bool has_next = nxt < n_items;
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // steps 0, 1: the epilogue of the previous tile may still be in flight behind stages 1 / 2
-        step(I3{}, T{}, T{}, ext, true, 1, 3, 3 * 32, wa, wb);
+        step(I6{}, T{}, T{}, ext, true, 1, 3, 3 * 32, wa, wb);
         step(I3{}, T{}, T{}, ext, true, 2, 0, 4 * 32, wb, wa);
         int s = 2;
         for (; s + 4 < ns; s += 2) {
