@@ -239,7 +239,7 @@ int p2t_adapter_backward(const p2t_adapter_config* cfg, const p2t_adapter_weight
 
 /* ---------------------------------------------------------------- readout / normalise / loss */
 /* emb [B, T, ld] (`dtype`, or f32), mask int64 [B, T] (NULL = all ones) -> out f32 [B, D] (mean/std/last)
- * or [B, 2D] (mix). */
+ * or [B, 2D] (mix).  D and ld must be multiples of 4 (vector loads). */
 int p2t_readout(const void* emb, int dtype, int64_t ld, const int64_t* mask, int B, int T, int D, int mode,
                 float* out, p2t_stream stream);
 /* d_out f32 [B, D or 2D] -> d_emb f32 [B, T, D]. */

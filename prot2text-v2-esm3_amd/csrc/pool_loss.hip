@@ -7,96 +7,143 @@
 
 namespace p2t {
 
-// grid (ceil(D/64), B), block 256 = 64 columns x 4 row stripes.  Two passes over the (b, 64-column)
-// slab exactly as the reference does (mean first, then the masked squared deviations).
+// grid (ceil(D/64), B), block 256: a wave reads 4 rows x 64 columns per instruction (lane = 16 column quads x 4 rows,
+// 8 or 16 bytes per lane), the four waves stripe the rows.  Two passes over the (b, 64-column) slab exactly as the
+// reference does (mean first, then the masked squared deviations); requires D % 4 == 0.
 template <typename T>
 __global__ void __launch_bounds__(256) readout_kernel(const T* __restrict__ emb, int64_t ld, const int64_t* __restrict__ mask,
                                                       int seq, int D, int mode, float* __restrict__ out) {
     __shared__ float part[4][64];
-    const int b = blockIdx.y, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cq = lane & 15, rq = lane >> 4;               // column quad, row inside the wave's 4-row group
+    const int c = blockIdx.x * 64 + cq * 4;
     const T* base = emb + (int64_t)b * seq * ld;
     const int64_t* mrow = mask ? mask + (int64_t)b * seq : nullptr;
     // count of the mask (every wave computes it redundantly from its lanes)
     float cnt = 0.f;
-    for (int t = tx; t < seq; t += 64) cnt += mrow ? (float)mrow[t] : 1.f;
+    for (int t = lane; t < seq; t += 64) cnt += mrow ? (float)mrow[t] : 1.f;
     cnt = wave_sum(cnt);
     const int out_ld = mode == P2T_READOUT_MIX ? 2 * D : D;
     if (mode == P2T_READOUT_LAST) {
         const int idx = (int)cnt - 1;
-        if (ty == 0 && c < D && idx >= 0) out[(int64_t)b * out_ld + c] = to_f32(base[(int64_t)idx * ld + c]);
-        return;
-    }
-    float s = 0.f;
-    if (c < D)
-        for (int t = ty; t < seq; t += 4) s += to_f32(base[(int64_t)t * ld + c]) * (mrow ? (float)mrow[t] : 1.f);
-    part[ty][tx] = s;
-    __syncthreads();
-    const float mean = (part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]) / cnt;
-    if (mode == P2T_READOUT_MEAN) {
-        if (ty == 0 && c < D) out[(int64_t)b * out_ld + c] = mean;
-        return;
-    }
-    __syncthreads();
-    float qd = 0.f;
-    if (c < D)
-        for (int t = ty; t < seq; t += 4) {
-            const float dlt = to_f32(base[(int64_t)t * ld + c]) - mean;
-            qd += dlt * dlt * (mrow ? (float)mrow[t] : 1.f);
+        if (w == 0 && rq == 0 && c < D && idx >= 0) {
+            float v[4];
+            load4(base + (int64_t)idx * ld + c, v);
+            store4(out + (int64_t)b * out_ld + c, v);
         }
-    part[ty][tx] = qd;
-    __syncthreads();
-    if (ty == 0 && c < D) {
-        const float sd = sqrtf((part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]) / cnt);
+        return;
+    }
+    // column sums over this wave's rows, then over the 4 row groups (lanes 16 apart) and the 4 waves
+    auto reduce = [&](float (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] += __shfl_xor(v[j], 16, 64);
+            v[j] += __shfl_xor(v[j], 32, 64);
+        }
+        __syncthreads();
+        if (rq == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[w][cq * 4 + j] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = part[0][cq * 4 + j] + part[1][cq * 4 + j] + part[2][cq * 4 + j] + part[3][cq * 4 + j];
+    };
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < D)
+        for (int t = w * 4 + rq; t < seq; t += 16) {
+            const float mk = mrow ? (float)mrow[t] : 1.f;
+            float v[4];
+            load4(base + (int64_t)t * ld + c, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += v[j] * mk;
+        }
+    reduce(s);
+    float mean[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mean[j] = s[j] / cnt;
+    if (mode == P2T_READOUT_MEAN) {
+        if (w == 0 && rq == 0 && c < D) store4(out + (int64_t)b * out_ld + c, mean);
+        return;
+    }
+    float qd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < D)
+        for (int t = w * 4 + rq; t < seq; t += 16) {
+            const float mk = mrow ? (float)mrow[t] : 1.f;
+            float v[4];
+            load4(base + (int64_t)t * ld + c, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dlt = v[j] - mean[j];
+                qd[j] += dlt * dlt * mk;
+            }
+        }
+    reduce(qd);
+    if (w == 0 && rq == 0 && c < D) {
+        float sd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sd[j] = sqrtf(qd[j] / cnt);
         if (mode == P2T_READOUT_STD) {
-            out[(int64_t)b * out_ld + c] = sd;
+            store4(out + (int64_t)b * out_ld + c, sd);
         } else {
-            out[(int64_t)b * out_ld + c] = mean;
-            out[(int64_t)b * out_ld + D + c] = sd;
+            store4(out + (int64_t)b * out_ld + c, mean);
+            store4(out + (int64_t)b * out_ld + D + c, sd);
         }
     }
 }
 
 // d_emb[b,t,c] = m_t * ( dmean_c / cnt + dstd_c * (x - mean_c) / (cnt * std_c) ); "last": scatter.
+// A wave owns 4 x 64 columns and walks kRowsPerBlock / 4 rows: the per-column coefficients (two divisions each) are
+// formed once per wave instead of once per element, so the pass is the HBM stream it should be (2 B read + 4 B written
+// per element) rather than a division loop.
+constexpr int kReadoutBwdRows = 32;
 template <typename T>
 __global__ void __launch_bounds__(256) readout_bwd_kernel(const T* __restrict__ emb, int64_t ld, const int64_t* __restrict__ mask,
                                                           int seq, int D, int mode, const float* __restrict__ pooled,
                                                           const float* __restrict__ d_out, float* __restrict__ d_emb) {
-    const int b = blockIdx.z, lane = threadIdx.x & 63;
+    const int b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t* mrow = mask ? mask + (int64_t)b * seq : nullptr;
     float cnt = 0.f;
     for (int t = lane; t < seq; t += 64) cnt += mrow ? (float)mrow[t] : 1.f;
     cnt = wave_sum(cnt);
-    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (t >= seq) return;
-    const float mk = mrow ? (float)mrow[t] : 1.f;
+    const int c = blockIdx.x * 256 + lane * 4;
+    if (c >= D) return;
     const int out_ld = mode == P2T_READOUT_MIX ? 2 * D : D;
     const float* po = pooled ? pooled + (int64_t)b * 2 * D : nullptr;
     const float* go = d_out + (int64_t)b * out_ld;
-    const T* x = emb + ((int64_t)b * seq + t) * ld;
-    float* g = d_emb + ((int64_t)b * seq + t) * D;
-    const int c = blockIdx.x * 256 + lane * 4;
-    if (c >= D) return;
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    // r = (ca + cb * (x - cm)) * m_t
+    float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f}, cm[4] = {0.f, 0.f, 0.f, 0.f}, glast[4] = {0.f, 0.f, 0.f, 0.f};
     if (mode == P2T_READOUT_LAST) {
-        if (t == (int)cnt - 1) load4(go + c, r);
+        load4(go + c, glast);
     } else {
-        float xv[4];
-        load4(x + c, xv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float acc = 0.f;
-            if (mode == P2T_READOUT_MEAN || mode == P2T_READOUT_MIX) acc = go[c + j] / cnt;
+            if (mode == P2T_READOUT_MEAN || mode == P2T_READOUT_MIX) ca[j] = go[c + j] / cnt;
             if (mode == P2T_READOUT_STD || mode == P2T_READOUT_MIX) {
                 // `pooled` is the forward [mean | std] (2D wide) for both modes
-                const float mean = po[c + j], sd = po[D + c + j];
+                const float sd = po[D + c + j];
                 const float gs = mode == P2T_READOUT_MIX ? go[D + c + j] : go[c + j];
-                acc += gs * (xv[j] - mean) / (cnt * sd);
+                cm[j] = po[c + j];
+                cb[j] = gs / (cnt * sd);
             }
-            r[j] = acc * mk;
         }
     }
-    store4(g + c, r);
+    const int t0 = blockIdx.y * kReadoutBwdRows;
+    for (int t = t0 + w; t < t0 + kReadoutBwdRows && t < seq; t += 4) {
+        const float mk = mrow ? (float)mrow[t] : 1.f;
+        float* g = d_emb + ((int64_t)b * seq + t) * D;
+        float r[4];
+        if (mode == P2T_READOUT_LAST) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = t == (int)cnt - 1 ? glast[j] : 0.f;
+        } else {
+            float xv[4];
+            load4(emb + ((int64_t)b * seq + t) * ld + c, xv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (ca[j] + cb[j] * (xv[j] - cm[j])) * mk;
+        }
+        store4(g + c, r);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -190,6 +237,7 @@ using namespace p2t;
 extern "C" int p2t_readout(const void* emb, int dtype, int64_t ld, const int64_t* mask, int B, int T, int D, int mode,
                            float* out, p2t_stream stream) {
     P2T_REQUIRE(emb && out && B > 0 && T > 0 && D > 0 && ld >= D && mode >= 0 && mode <= 3, "p2t_readout: bad arguments");
+    P2T_REQUIRE(D % 4 == 0 && ld % 4 == 0, "p2t_readout: D and ld must be multiples of 4 (D=%d ld=%lld)", D, (long long)ld);
     const dim3 grid((unsigned)ceil_div(D, 64), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == P2T_BF16)
@@ -206,7 +254,7 @@ extern "C" int p2t_readout_backward(const void* emb, int dtype, int64_t ld, cons
                 "p2t_readout_backward: bad arguments (D and ld must be multiples of 4)");
     P2T_REQUIRE(pooled || mode == P2T_READOUT_LAST || mode == P2T_READOUT_MEAN,
                 "p2t_readout_backward: std/mix need the forward [mean | std] (2D wide) in `pooled`");
-    const dim3 grid((unsigned)ceil_div(D, 256), (unsigned)ceil_div(T, 4), (unsigned)B);
+    const dim3 grid((unsigned)ceil_div(D, 256), (unsigned)ceil_div(T, kReadoutBwdRows), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == P2T_BF16)
         readout_bwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)emb, ld, mask, T, D, mode, pooled, d_out, d_emb);
