@@ -562,7 +562,9 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
         if (eligible && pick) {
             int64_t n_full = items, n_tail = 0;
             SplitFix fix{};
-            const bool worth = tile == 3 || ns >= 128;
+            // the fix-up tiles run un-overlapped after the tile loop (~50 us): it pays when half a tile time is well above that
+            // (K = 10240: +7 %), not at K = 4096 (SwiGLU GEMM of the text tower, 3.5 rounds: -7 %)
+            const bool worth = tile == 3 || ns >= 192;
             if (tile != 4 && fix_ws && rem > 0 && rem <= 128 && (ns & 7) == 0 && worth && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
                 n_full = items - rem;
                 n_tail = rem;
