@@ -312,8 +312,9 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
     halves (producer slab -> consumer epilogue).  Must equal the plain kernel bit for bit in structure-independent
     terms (same fp32 sums up to the order of the two K halves) and the oracle; repeated launches reuse the flags.
     Both kernels that implement it: the persistent one (default for this shape) and the one-block-per-tile one."""
-    if path == "per_tile":
-        monkeypatch.setenv("P2T_GEMM_TILE", "2")
+    # 2: per-tile kernels only; 3: persistent kernel with the fix-up whenever possible (the default policy only uses it
+    # from K = 6144 up, where it pays)
+    monkeypatch.setenv("P2T_GEMM_TILE", "2" if path == "per_tile" else "3")
     M, N, K = shape                                               # 640 tiles = 2.5 rounds / 336 tiles = 1 round + 80
     n_tail = ((M // 256) * (N // 256)) % 256
     a, w = bf16r(rnd(12, "s.a", (M, K), 1.0)), bf16r(rnd(12, "s.w", (N, K), 0.3))
