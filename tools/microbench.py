@@ -62,6 +62,41 @@ def bench_gemm():
               f"persistent {fl / res[2]:7.1f} | persistent+splitK {fl / res[3]:7.1f} | default {fl / res[4]:7.1f} ({res[4]:.3f} ms)", flush=True)
 
 
+def bench_cold():
+    """Encoder GEMMs with their operands / residual stream COLD (a 768 MB fill between launches evicts the 256 MB Infinity
+    Cache), as they are inside a step; each launch timed on its own with events."""
+    shapes = [("esm qkv", 16384, 7680, 2560, 0), ("esm o", 16384, 2560, 2560, 2), ("esm fc1", 16384, 10240, 2560, 1),
+              ("esm fc2", 16384, 2560, 10240, 2)]
+    flush = torch.empty((768 << 20,), dtype=torch.uint8, device=dev)
+    for name, M, N, K, epi in shapes:
+        a, w = rand((M, K)), rand((N, K), scale=0.05)
+        bias = rand((N,), torch.float32, 0.1)
+        out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
+        ws, ep = ops.gemm_fix_workspace(dev), [0]
+        fl = 2.0 * M * N * K / 1e9
+        res = []
+        for env in ("2", "4", "3", None):
+            if env is None:
+                os.environ.pop("P2T_GEMM_TILE", None)
+            else:
+                os.environ["P2T_GEMM_TILE"] = env
+            tot = 0.0
+            for i in range(6):
+                flush.fill_(i)
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ep[0] += 1
+                s0.record()
+                ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1, fix_ws=ws, fix_epoch=ep[0])
+                e0.record()
+                torch.cuda.synchronize()
+                if i > 0:
+                    tot += s0.elapsed_time(e0)
+            res.append(tot / 5)
+        os.environ.pop("P2T_GEMM_TILE", None)
+        print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
+              f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | default {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f}", flush=True)
+
+
 def bench_ksweep():
     """Per-tile fixed cost vs steady-state rate: time = rounds * (a + b*K)."""
     for epi in (0, 1, 2):
@@ -103,6 +138,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "gemm" in which:
         bench_gemm()
+    if "cold" in which:
+        bench_cold()
     if "ksweep" in which:
         bench_ksweep()
     if "attn" in which:
