@@ -584,6 +584,22 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);
     const double cost128 = (double)ceil_div(tm128 * tn, kCUs) * kSmallTileCost * 1.08;
+    if (tile == 0 && fix_ws && tm256 * tn * 2 <= kCUs && tm256 * tn * 8 >= kCUs * 3 && (K >> 5) >= 256 &&
+        fix_bytes >= kFixHeader + (size_t)(tm256 * tn) * kFixSlab) {
+        // at most half a round of 256-row tiles and a long K (FFN-down of the text tower: 128 tiles, K = 14336): every
+        // tile as two K halves on two CUs (half a tile time + the slab hand-off) instead of a full round of 128-row
+        // tiles (0.675 tile times)
+        SplitFix fix;
+        fix.flag = (unsigned*)fix_ws;
+        fix.timeout = (unsigned*)((char*)fix_ws + 1024);
+        fix.slab = (float*)((char*)fix_ws + kFixHeader);
+        fix.epoch = fix_epoch;
+        const int64_t n_tail = tm256 * tn;
+        gemm_nt_mfma_tail_kernel<Epi><<<dim3((unsigned)(2 * n_tail)), 512, 0, s>>>(
+            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)tm256, (int)tn, 0, (int)n_tail, n_cover, ep, fix);
+        P2T_LAUNCH_CHECK();
+        return P2T_OK;
+    }
     if (tile == 256 || (tile != 128 && cost256 <= cost128)) {
         // split-K tail: leftover tiles of the last partial round (at most half a round) run as two K halves each
         const int64_t total = tm256 * tn, n_full = (total / kCUs) * kCUs, n_tail = total - n_full;

@@ -44,7 +44,7 @@ size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b
 
 struct LlamaBuffers {
     uint8_t* key_mask; int32_t* kv_info; float* inv_freq; float* cs;
-    float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* act;
+    float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* act; void* fix;
 };
 
 size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffers* b) {
@@ -67,6 +67,7 @@ size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffe
     t.v = a.take(e * (size_t)B * nkv * T * dp);
     t.ao = a.take(e * (size_t)M * QO);
     t.act = a.take(e * (size_t)M * Fp);
+    t.fix = a.take(gemm_fix_workspace_bytes());
     if (b) *b = t;
     return a.off + 256;
 }
@@ -183,6 +184,9 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
     }
     P2T_TRY(launch_rope_table(inv_freq, T, d / 2, b.cs, s));
     const float scale = 1.0f / sqrtf((float)d);
+    P2T_CHECK_HIP(hipMemsetAsync(b.fix, 0, gemm_fix_header_bytes(), s));      // split-K flags; epochs below are unique
+    unsigned epoch = 0;
+    auto with_fix = [&](GemmArgs& g) { g.fix_ws = b.fix; g.fix_bytes = gemm_fix_workspace_bytes(); g.fix_epoch = ++epoch; };
     for (int l = 0; l < k; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
@@ -202,6 +206,7 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
         GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, b.act, Fp, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_SWIGLU, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g3, s));
         GemmArgs g4{b.act, Fp, L.down_w, Fp, nullptr, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
+        with_fix(g4);
         P2T_TRY(gemm_nt(g4, s));
     }
     if (k == c->n_layers) return launch_rmsnorm(b.x, H, w->final_norm_w, c->rms_norm_eps, out, H, M, H, P2T_F32, s);

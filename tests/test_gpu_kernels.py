@@ -304,7 +304,7 @@ def test_clip_adamw(ops, max_norm):
     assert np.array_equal(to_np(sh2)[:, :48], bf16r(to_np(dp[2])))
 
 
-@pytest.mark.parametrize("shape", [(16384, 2560, 4096), (4096, 5376, 4096)])
+@pytest.mark.parametrize("shape", [(16384, 2560, 4096), (4096, 5376, 4096), (2048, 4096, 8192)])
 @pytest.mark.parametrize("path", ["persistent", "per_tile"])
 @pytest.mark.parametrize("epi", [EPI_STORE, EPI_RESID, EPI_GELU])
 def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
@@ -315,7 +315,7 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
     # 2: per-tile kernels only; 3: persistent kernel with the fix-up whenever possible (the default policy only uses it
     # from K = 6144 up, where it pays)
     monkeypatch.setenv("P2T_GEMM_TILE", "2" if path == "per_tile" else "3")
-    M, N, K = shape                                               # 640 tiles = 2.5 rounds / 336 tiles = 1 round + 80
+    M, N, K = shape                 # 640 tiles = 2.5 rounds / 336 tiles = 1 round + 80 / 128 tiles, all split (long K)
     n_tail = ((M // 256) * (N // 256)) % 256
     a, w = bf16r(rnd(12, "s.a", (M, K), 1.0)), bf16r(rnd(12, "s.w", (N, K), 0.3))
     bias = rnd(12, "s.b", (N,), 0.3)
