@@ -158,7 +158,9 @@ typedef struct {
     int32_t dtype;
 } p2t_llama_config;
 
-/* qkv_w rows: q (heads*d), k (kv*d), v (kv*d).  gu_w: gate/up interleaved in blocks of 32 rows
+/* qkv_w rows: q (heads*d), k (kv*d), v (kv*d); for head_dim 128 the 128 rows of EVERY head are stored in the order
+ * 0..31, 64..95, 32..63, 96..127 (the rotary partners j, j+64 then sit 32 rows apart inside a 64-row block, which is what
+ * the fused QKV + RoPE epilogue pairs up); natural order for every other head_dim.  gu_w: gate/up interleaved in blocks of 32 rows
  * (rows 64j..64j+31 = gate features 32j.., rows 64j+32..64j+63 = up features 32j..).  No biases. */
 typedef struct {
     const void* qkv_w; const void* o_w; const void* gu_w; const void* down_w;

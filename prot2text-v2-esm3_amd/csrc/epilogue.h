@@ -28,6 +28,7 @@ struct EpiParams {
     const float* cs;        // [T, 64]: cos (32) | sin (32)
     void* q; void* k; void* v;
     int seq, nh, nkv;
+    int head_dim;           // 64, or 128 with the packed row order of include/p2t_hip.h (p2t_llama_layer)
     float q_scale;
 };
 
@@ -235,9 +236,12 @@ struct EpiSwiglu {
     }
 };
 
-// QKV projection + bias + query scale + rotary (rotate-half pairs j, j+32 of a 64-wide head) + head split:
-// q [B, nh, T, 64], k [B, nkv, T, 64], v [B, nkv, T, 64].  Restates HF EsmSelfAttention.forward up to the
-// attention call (modeling_esm.py:362-378) and LlamaAttention.forward (modeling_llama.py:254-259) for d = 64.
+// QKV projection + bias + query scale + rotary + head split: q [B, nh, T, d], k [B, nkv, T, d], v [B, nkv, T, d], d = 64 or 128.
+// The kernels hand a lane the columns n .. n+W-1 and n+32 .. n+32+W-1 of a 64-column block.  d = 64: the block is a head
+// and the partner IS the rotate-half partner (j, j+32).  d = 128: the weight rows of every head are PACKED in the order
+// 0..31, 64..95, 32..63, 96..127, so block 2h holds the channels (j, j+64) for j < 32 and block 2h+1 those for 32 <= j < 64
+// -- again (first group, partner group).  Restates HF EsmSelfAttention.forward up to the attention call
+// (modeling_esm.py:362-378) and LlamaAttention.forward (modeling_llama.py:254-259).
 template <typename Tout>
 struct EpiQkvRope {
     static constexpr bool kRmw = false;
@@ -246,7 +250,10 @@ struct EpiQkvRope {
     __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
                                                   const float (&b0)[W], const float (&b1)[W]) {
         if (n >= p.N) return;
-        const int head = n >> 6, j = n & 31;
+        const int hd = p.head_dim, half = hd >> 1;
+        const int blk = n >> 6;
+        const int head = hd == 64 ? blk : blk >> 1;
+        const int j = (hd == 64 ? 0 : 32 * (blk & 1)) + (n & 31);          // rotary channel: pairs (j, j + hd/2)
         const int b = (int)(m / p.seq), t = (int)(m - (int64_t)b * p.seq);
         float x1[W], x2[W];
 #pragma unroll
@@ -256,22 +263,22 @@ struct EpiQkvRope {
             const bool is_q = head < p.nh;
             const float sc = is_q ? p.q_scale : 1.0f;
             float c[W], s[W], o1[W], o2[W];
-            loadW<W>(p.cs + (int64_t)t * 64 + j, c);
-            loadW<W>(p.cs + (int64_t)t * 64 + 32 + j, s);
+            loadW<W>(p.cs + (int64_t)t * hd + j, c);
+            loadW<W>(p.cs + (int64_t)t * hd + half + j, s);
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 const float a1 = x1[e] * sc, a2 = x2[e] * sc;
                 o1[e] = a1 * c[e] - a2 * s[e];
                 o2[e] = a2 * c[e] + a1 * s[e];
             }
-            dst = is_q ? (Tout*)p.q + (((int64_t)b * p.nh + head) * p.seq + t) * 64
-                       : (Tout*)p.k + (((int64_t)b * p.nkv + (head - p.nh)) * p.seq + t) * 64;
+            dst = is_q ? (Tout*)p.q + (((int64_t)b * p.nh + head) * p.seq + t) * hd
+                       : (Tout*)p.k + (((int64_t)b * p.nkv + (head - p.nh)) * p.seq + t) * hd;
             storeW<W>(dst + j, o1);
-            storeW<W>(dst + 32 + j, o2);
+            storeW<W>(dst + half + j, o2);
         } else {
-            dst = (Tout*)p.v + (((int64_t)b * p.nkv + (head - p.nh - p.nkv)) * p.seq + t) * 64;
+            dst = (Tout*)p.v + (((int64_t)b * p.nkv + (head - p.nh - p.nkv)) * p.seq + t) * hd;
             storeW<W>(dst + j, x1);
-            storeW<W>(dst + 32 + j, x2);
+            storeW<W>(dst + half + j, x2);
         }
     }
 };

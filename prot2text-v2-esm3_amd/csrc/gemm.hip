@@ -44,8 +44,9 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     const bool swiglu = a.epilogue == P2T_EPI_SWIGLU;
     const bool rope = a.epilogue == P2T_EPI_QKV_ROPE;
     P2T_REQUIRE(a.N % ((swiglu || rope) ? 64 : 16) == 0, "gemm_nt: N=%lld must be a multiple of %d", (long long)a.N, (swiglu || rope) ? 64 : 16);
-    P2T_REQUIRE(!rope || (a.cs && a.q && a.k && a.v && a.seq > 0 && a.N == (int64_t)(a.nh + 2 * a.nkv) * 64 && a.M % a.seq == 0),
-                "gemm_nt: EPI_QKV_ROPE needs head_dim 64 outputs, the rotary table and M = B * seq");
+    P2T_REQUIRE(!rope || (a.cs && a.q && a.k && a.v && a.seq > 0 && (a.head_dim == 64 || a.head_dim == 128) &&
+                          a.N == (int64_t)(a.nh + 2 * a.nkv) * a.head_dim && a.M % a.seq == 0),
+                "gemm_nt: EPI_QKV_ROPE needs head_dim 64 or 128 outputs, the rotary table and M = B * seq");
     P2T_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0 && a.lda >= a.K && a.ldw >= a.K,
                 "gemm_nt: K and the row strides must be multiples of 4 (K=%lld lda=%lld ldw=%lld ldc=%lld)", (long long)a.K,
                 (long long)a.lda, (long long)a.ldw, (long long)a.ldc);
@@ -66,7 +67,7 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     ep.bias = a.bias; ep.out = a.out; ep.z = a.z; ep.ldc = a.ldc; ep.M = a.M; ep.N = (int)a.N; ep.n_zero = n_zero;
     ep.accumulate = a.accumulate; ep.drop_p = a.drop_p; ep.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     ep.drop_seed = a.drop_seed;
-    ep.cs = a.cs; ep.q = a.q; ep.k = a.k; ep.v = a.v; ep.seq = a.seq; ep.nh = a.nh; ep.nkv = a.nkv; ep.q_scale = a.q_scale;
+    ep.cs = a.cs; ep.q = a.q; ep.k = a.k; ep.v = a.v; ep.seq = a.seq; ep.nh = a.nh; ep.nkv = a.nkv; ep.q_scale = a.q_scale; ep.head_dim = a.head_dim;
 
     const bool aligned = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0);
     const bool can_mfma = a.dtype == P2T_BF16 && a.K % 64 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && aligned;

@@ -42,9 +42,9 @@ struct GemmArgs {
     int n_zero;                 // -1: default (next multiple of 64, clipped to ldc)
     float drop_p; uint64_t drop_seed;
     int tile;                   // 0 auto, 128, 256 (rows of the MFMA block tile)
-    // P2T_EPI_QKV_ROPE only (head_dim 64): rotary table [T, 64], outputs [B, heads, T, 64]
+    // P2T_EPI_QKV_ROPE only (head_dim 64 or 128): rotary table [T, head_dim], outputs [B, heads, T, head_dim]
     const float* cs = nullptr; void* q = nullptr; void* k = nullptr; void* v = nullptr;
-    int seq = 0, nh = 0, nkv = 0; float q_scale = 1.f;
+    int seq = 0, nh = 0, nkv = 0; float q_scale = 1.f; int head_dim = 64;
     // optional split-K tail fix-up (MFMA kernel, 256-row tiles): workspace + an epoch unique since its header was zeroed
     void* fix_ws = nullptr; size_t fix_bytes = 0; unsigned fix_epoch = 0;
 };

@@ -190,9 +190,10 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
     for (int l = 0; l < k; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
-        if (d == 64) {
+        if (d == 64 || d == 128) {
+            // bias-free QKV projection + rotary + head split in the GEMM epilogue (d = 128: rows packed per head, see the header)
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, nullptr, 0, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_QKV_ROPE, 0, -1, -1, 0.f, 0, 0};
-            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f;
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f; g1.head_dim = d;
             P2T_TRY(gemm_nt(g1, s));
         } else {
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};

@@ -395,6 +395,8 @@ class LlamaTextModel(nn.Module):
         for i in range(n_layers):
             p = f"layers.{i}."
             qkv = torch.cat([P[p + f"self_attn.{n}_proj.weight"].detach() for n in ("q", "k", "v")], 0)
+            if d == 128:        # per head: rows 0..31, 64..95, 32..63, 96..127 (include/p2t_hip.h, p2t_llama_layer)
+                qkv = qkv.view(-1, 2, 2, 32, H).transpose(1, 2).reshape(-1, H)
             gate, up = P[p + "mlp.gate_proj.weight"].detach(), P[p + "mlp.up_proj.weight"].detach()
             gu = torch.stack([gate.view(F // 32, 32, H), up.view(F // 32, 32, H)], 1).reshape(2 * F, H)   # 32-row gate/up blocks
             t = dict(qkv_w=_pad_cols(qkv, Hp, dt), o_w=_pad_cols(P[p + "self_attn.o_proj.weight"], QO, dt),

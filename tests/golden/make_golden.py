@@ -401,7 +401,7 @@ def run_sft(ref):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,cfg1,collate,train_state,sft")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,cfg1,collate,train_state,sft")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -429,6 +429,14 @@ def main():
         ad = specs.AdapterSpec(96, 80, 128, 0.3)
         run_case(ref, "tiny_d24", esm, llama, ad, B=6, T_p=40, T_t=20, p_lens=[40, 33, 21, 10, 4, 2],
                  t_lens=[20, 20, 13, 7, 3, 1], layers=[1, 2], id_high=290, pad_id=299, eos_id=298)
+    if "tiny_d128" in only:
+        # text tower with head_dim 128 (Llama-3.1-8B's): fused QKV + rotary epilogue with the packed row order, GQA 2:1
+        esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+        llama = specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=192, num_attention_heads=2,
+                                num_key_value_heads=1, vocab_size=300)
+        ad = specs.AdapterSpec(64, 80, 256, 0.3)
+        run_case(ref, "tiny_d128", esm, llama, ad, B=4, T_p=24, T_t=40, p_lens=[24, 15, 7, 3], t_lens=[40, 33, 9, 2],
+                 layers=[1, 2], id_high=290, pad_id=299, eos_id=298)
     if "cfg1" in only:
         name_e, name_l, _, B, T_p, T_t = specs.CONFIGS["cfg1"]
         esm, llama = specs.esm_spec(name_e), specs.llama_spec(name_l)
