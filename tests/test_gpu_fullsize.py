@@ -128,3 +128,19 @@ def test_cfg3_bf16_pipeline_vs_exact_fp32_pipeline(cfg3):
     torch.cuda.empty_cache()
     assert rel(t16, t32) < 3e-2
     assert rel(p16, p32) < 5e-2                                                  # 36 layers of bf16 storage
+
+
+def test_cfg3_batch_size_invariance_across_kernel_forms(cfg3):
+    """The same sequences inside a large batch (persistent GEMM kernels: 16 x 1024 residues, 64 x 128 tokens) and inside a
+    small one (per-tile kernels) give the same embeddings: rows never interact, whichever launch form computes them."""
+    P, model = cfg3["P"], cfg3["model"]
+    Tp, Tt = cfg3["Tp"], cfg3["Tt"]
+    pid, pmask = synth.protein_batch(41, 16, Tp, [Tp - 7 * i for i in range(16)])
+    tid, tmask = synth.text_batch(41, 64, Tt, 128000, [Tt - (i % 50) for i in range(64)], 128002, 128009)
+    with torch.no_grad():
+        pe = lambda i, m: to_np(P.l2_normalize(P.get_sequence_embeddings(model, to_dev(i), to_dev(m))))
+        te = lambda i, m: to_np(P.l2_normalize(P.get_description_embeddings(model, to_dev(i), to_dev(m), 16)))
+        p_big, t_big = pe(pid, pmask), te(tid, tmask)
+        p_small, t_small = pe(pid[5:7], pmask[5:7]), te(tid[20:24], tmask[20:24])
+    assert rel(p_big[5:7], p_small) < 1e-3
+    assert rel(t_big[20:24], t_small) < 1e-3
