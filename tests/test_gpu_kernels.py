@@ -332,3 +332,32 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
     monkeypatch.setenv("P2T_GEMM_TILE", "2")                      # plain per-tile kernel, no workspace
     plain = to_np(ops.gemm_nt(ad, wd, bd, epilogue=epi, out=to_dev(resid) if epi == EPI_RESID else None, use_mfma=1))
     assert rel(got[:, :N], plain[:, :N]) < (1e-6 if epi == EPI_RESID else 2e-3)
+
+
+@pytest.mark.parametrize("tile", ["0", "3", "4"])
+def test_gemm_persistent_forms_fuzz(ops, tile, monkeypatch):
+    """Random whole-tile shapes through the persistent kernel (default policy / split-K fix-up forced / no fix-up) against
+    the exact fp32-FMA kernel on the same bf16 operands: any stale LDS read or mis-counted wait shows up as a wrong tile."""
+    monkeypatch.setenv("P2T_GEMM_TILE", tile)
+    rng = np.random.default_rng(int(tile) + 7)
+    ws = ops.gemm_fix_workspace(dev())
+    epoch = 0
+    for _ in range(10):
+        tiles = int(rng.integers(256, 700))
+        tm = int(rng.choice([d for d in range(4, 65) if tiles // d >= 4]))
+        tn = max(4, tiles // tm)
+        M, N, K = 256 * tm, 256 * tn, 128 * int(rng.integers(3, 21))
+        a = torch.empty((M, K), dtype=torch.bfloat16, device=dev())
+        w = torch.empty((N, K), dtype=torch.bfloat16, device=dev())
+        ops.fill_hash_(a, 3, f"fz.a{M}x{K}", 1.0)
+        ops.fill_hash_(w, 3, f"fz.w{N}x{K}", 0.5)
+        b = to_dev(rnd(3, "fz.b", (N,), 0.3))
+        for epi in (EPI_STORE, EPI_RESID):
+            out0 = torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None
+            out1 = torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None
+            epoch += 1
+            got = ops.gemm_nt(a, w, b, epilogue=epi, out=out1, out_dtype=torch.float32, use_mfma=1, fix_ws=ws, fix_epoch=epoch)
+            ref = ops.gemm_nt(a, w, b, epilogue=epi, out=out0, out_dtype=torch.float32, use_mfma=0)
+            err = float((got[:, :N] - ref[:, :N]).abs().max() / ref[:, :N].abs().max())
+            assert err < 2e-5, (M, N, K, epi, err)
+    assert int(ws[1024:1028].view(torch.int32).item()) == 0                     # no split-K consumer timed out
