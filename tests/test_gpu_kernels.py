@@ -361,3 +361,32 @@ def test_gemm_persistent_forms_fuzz(ops, tile, monkeypatch):
             err = float((got[:, :N] - ref[:, :N]).abs().max() / ref[:, :N].abs().max())
             assert err < 2e-5, (M, N, K, epi, err)
     assert int(ws[1024:1028].view(torch.int32).item()) == 0                     # no split-K consumer timed out
+
+
+def test_attention_fuzz_mfma_vs_simple(ops):
+    """Random shapes / lengths / causal flags: the MFMA flash kernel (three-buffer prefetch, lazy rescale, XCD block order)
+    against the straightforward fp32-softmax kernel on the same bf16 q, k, v."""
+    rng = np.random.default_rng(11)
+    for it in range(24):
+        d = int(rng.choice([16, 24, 32, 64, 64, 128]))
+        nkv = int(rng.choice([1, 2, 4]))
+        nh = nkv * int(rng.choice([1, 2, 4]))
+        B = int(rng.integers(1, 4))
+        T = int(rng.integers(1, 330))
+        causal = bool(rng.integers(0, 2))
+        lens = [int(rng.integers(1, T + 1)) for _ in range(B)]
+        if it % 5 == 0:
+            lens[0] = T
+        mask = np.zeros((B, T), dtype=np.int64)
+        for b, n in enumerate(lens):
+            mask[b, :n] = 1
+        qkv = to_dev(bf16r(rnd(20 + it, "af.qkv", (B * T, (nh + 2 * nkv) * d), float(rng.choice([0.5, 1.5, 4.0])))), torch.bfloat16)
+        inv = to_dev(O.default_inv_freq(10000.0, d))
+        key_mask, kv_info, _ = ops.mask_prepare(to_dev(mask))
+        q, k, v = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0)
+        scale = float(d) ** -0.5
+        a = to_np(ops.attention(q, k, v, key_mask, kv_info, d, scale, causal, use_mfma=1)).reshape(B, T, -1)
+        r = to_np(ops.attention(q, k, v, key_mask, kv_info, d, scale, causal, use_mfma=0)).reshape(B, T, -1)
+        assert np.isfinite(a).all(), (it, B, T, nh, nkv, d, causal, lens)
+        for b, n in enumerate(lens):
+            assert rel(a[b, :n, :nh * d], r[b, :n, :nh * d]) < 1e-2, (it, B, T, nh, nkv, d, causal, lens)
