@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
 sys.path.insert(0, ROOT)
@@ -234,6 +236,38 @@ def main():
             tf64 = f["total"] * 64 / dt64 / 1e12
             out["config"]["batch64_check"] = {"samples_per_s": round(64 / dt64, 2), "ms_per_step": round(dt64 * 1e3, 2),
                                               "step_tflops": round(tf64, 1), "frac_of_bf16_peak": round(tf64 / PEAK_BF16_TFLOPS, 4)}
+        if world == 1 and not args.no_batch64_check and args.config in ("cfg3", "cfg4"):
+            # Ragged workload: 64 pairs with protein lengths from a clipped log-normal (median ~315
+            # residues, the shape of UniProt lengths; crop at 1024), once as the padded 64 x T_max step and once
+            # length-sorted (data.sort_batch_by_length) and cut into segments that each run at their own longest length
+            # (ContrastiveTrainer(trim_padding=True), contrastive.plan_length_segments).  Same loss by construction (tests/test_gpu_ragged.py).
+            from p2t_hip.data import sort_batch_by_length
+            rs = np.random.RandomState(0)
+            lens = np.clip(np.round(rs.lognormal(5.75, 0.6, 64)), 16, Tp).astype(int).tolist()
+            tl = np.clip(np.round(rs.lognormal(4.0, 0.5, 64)), 4, Tt).astype(int).tolist()
+            pidr, pmr = synth.protein_batch(77, 64, Tp, lens)
+            tidr, tmr = synth.text_batch(77, 64, Tt, lengths=tl)
+            Tmax = int(max(lens))
+            host = dict(protein_input_ids=torch.from_numpy(pidr[:, :Tmax].copy()), protein_attention_mask=torch.from_numpy(pmr[:, :Tmax].copy()),
+                        description_input_ids=torch.from_numpy(tidr), description_attention_mask=torch.from_numpy(tmr))
+            to_dev = lambda b: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+            padded, srt = to_dev(host), to_dev(sort_batch_by_length(host))
+            t_trim = P.ContrastiveTrainer(model, train_mode=not args.eval_mode, trim_padding=True)
+
+            def rate(tr, b):
+                tr.step(b)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(2):
+                    tr.step(b)
+                torch.cuda.synchronize()
+                return 64 * 2 / (time.perf_counter() - t)
+            r_pad, r_trim = rate(trainer, padded), rate(t_trim, srt)
+            out["config"]["ragged_check"] = {"lengths": "64 pairs, protein lengths lognormal(5.75, 0.6) clipped to [16, T_p]",
+                                             "mean_length": round(float(np.mean(lens)), 1), "longest": Tmax,
+                                             "padded_samples_per_s": round(r_pad, 2), "sorted_trimmed_samples_per_s": round(r_trim, 2),
+                                             "segments_rows_x_length": [[b - a, t] for a, b, t, _ in t_trim._segments(srt, 64, Tmax)]}
+            del t_trim
         if world == 1 and not args.no_batch64_check and not args.overlap:
             # the two towers on two HIP streams (ContrastiveTrainer(overlap_streams=True), `--overlap`): co-scheduled kernels
             # fill each other's partial rounds.  Not the default because per-kernel durations (roofline, rocprof) then

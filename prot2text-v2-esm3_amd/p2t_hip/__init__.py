@@ -19,7 +19,7 @@ __all__ = ["specs", "synth", "Esm2LlamaInstructConfig", "ModalityAdapterConfig",
            "Esm2LlamaInstructForCausalLM", "EsmEncoder", "LlamaDecoder", "BatchInfoNCELoss",
            "SegmentedBatchInfoNCELoss", "readout_embeddings", "l2_normalize", "get_sequence_embeddings",
            "get_description_embeddings", "teacher_forcing_forward_pass", "ContrastiveTrainer", "ops",
-           "EsmSequenceTokenizer", "ContrastiveCollater", "DevicePrefetcher", "CosineWarmupSchedule", "save_checkpoint",
+           "EsmSequenceTokenizer", "ContrastiveCollater", "DevicePrefetcher", "sort_batch_by_length", "CosineWarmupSchedule", "save_checkpoint",
            "load_model_checkpoint", "load_optimizer_scheduler_checkpoint"]
 
 _LAZY = {
@@ -29,7 +29,7 @@ _LAZY = {
     "readout_embeddings": "contrastive", "l2_normalize": "contrastive", "get_sequence_embeddings": "contrastive",
     "get_description_embeddings": "contrastive", "teacher_forcing_forward_pass": "contrastive",
     "ContrastiveTrainer": "contrastive",
-    "EsmSequenceTokenizer": "data", "ContrastiveCollater": "data", "DevicePrefetcher": "data",
+    "EsmSequenceTokenizer": "data", "ContrastiveCollater": "data", "DevicePrefetcher": "data", "sort_batch_by_length": "data",
     "CosineWarmupSchedule": "training_state", "save_checkpoint": "training_state",
     "load_model_checkpoint": "training_state", "load_optimizer_scheduler_checkpoint": "training_state",
 }

@@ -208,6 +208,41 @@ def teacher_forcing_forward_pass(rank, model, data_batch: Dict[str, Any], contra
 # ---------------------------------------------------------------------------------------------
 # fused training step
 # ---------------------------------------------------------------------------------------------
+def plan_length_segments(lengths, T: int, *, multiple: int = 128, max_tokens: Optional[int] = None,
+                         floor_tokens: int = 4096, overhead_tokens: int = 512):
+    """Split rows 0..B-1 (in the given order; sort by length first for the best result) into contiguous segments, each
+    run at its own padded length T_s = min(T, round_up(longest row of the segment, multiple)).
+
+    Dynamic programme over the cut points, minimising  sum_s [ max(n_s * T_s, floor_tokens) + overhead_tokens ]:
+    n_s * T_s is the segment's padded token count (what the encoder's GEMMs process), `floor_tokens` the size below
+    which a launch sequence no longer gets faster on 256 CUs (fewer tiles than CUs; 4096 measured best on the cfg3 step,
+    tools/ragged_sweep.py -> profiles/r01_ragged_sweep.log), and
+    `overhead_tokens` the per-segment fixed cost (weights re-read from HBM, ~200 launches) in token equivalents.
+    `max_tokens` caps a segment (activation memory); a single row is always allowed.  -> [(start, stop, T_s)]."""
+    n = len(lengths)
+    if n == 0:
+        return []
+    pad = [min(T, round_up(max(1, int(v)), multiple)) for v in lengths]
+    best = [0.0] + [math.inf] * n
+    cut = [0] * (n + 1)
+    for j in range(1, n + 1):
+        longest = 0
+        for i in range(j - 1, -1, -1):
+            longest = max(longest, pad[i])
+            tokens = round_up((j - i) * longest, 256)          # GEMM row tiles
+            if max_tokens is not None and tokens > max_tokens and j - i > 1:
+                break
+            cost = best[i] + max(tokens, floor_tokens) + overhead_tokens
+            if cost < best[j]:
+                best[j], cut[j] = cost, i
+    out, j = [], n
+    while j > 0:
+        i = cut[j]
+        out.append((i, j, max(pad[i:j])))
+        j = i
+    return out[::-1]
+
+
 class ContrastiveTrainer:
     """The timed step: forward + adapter backward + clip + AdamW in one enqueue sequence.
 
@@ -222,7 +257,14 @@ class ContrastiveTrainer:
     def __init__(self, model, *, lr=2e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=None,
                  num_segments: int = 1, output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
                  temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None,
-                 overlap_streams: bool = False, schedule=None):
+                 overlap_streams: bool = False, schedule=None, trim_padding: bool = False, trim_multiple: int = 128,
+                 trim_floor_tokens: int = 4096):
+        if trim_padding and ones_mask:
+            raise ValueError("trim_padding needs the mask-aware readout: with ones_mask=True (the fork's quirk, "
+                             "train_contrast.py:269-275) the padded positions are part of the result")
+        if trim_multiple <= 0 or trim_multiple % 64:
+            raise ValueError("trim_multiple must be a positive multiple of 64")
+        self.trim_padding, self.trim_multiple, self.trim_floor_tokens = trim_padding, trim_multiple, trim_floor_tokens
         self.model = model
         self.schedule = schedule                   # training_state.CosineWarmupSchedule or None (constant lr)
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
@@ -265,22 +307,25 @@ class ContrastiveTrainer:
 
     # ------------------------------------------------------------------------------------------
     def _buffers(self, Bs: int, T: int):
-        key = (Bs, T)
-        b = self._buf.get(key)
-        if b is None:
+        """Adapter activations / gradients for M = Bs * T rows: ONE grow-only set sized for the largest M seen, handed
+        out as leading-row views, so ragged segment shapes (trim_padding) do not multiply the footprint."""
+        M = Bs * T
+        cap = self._buf.get("cap", 0)
+        if M > cap:
             c, dev, dt = self.c, self.dev, self.tdt
-            M = Bs * T
             ld1, ld2 = round_up(c.intermediate_dim, 64), round_up(c.output_dim, 64)
             e = lambda *s, d=dt: torch.empty(s, dtype=d, device=dev)
-            b = dict(z1=e(M, ld1), h1=e(M, ld1), z2=e(M, ld2), g2=e(M, ld2), y=e(M, ld2),
-                     inv=e(M, d=torch.float32), dY=e(M, c.output_dim, d=torch.float32))
+            full = dict(z1=e(M, ld1), h1=e(M, ld1), z2=e(M, ld2), g2=e(M, ld2), y=e(M, ld2),
+                        inv=e(M, d=torch.float32), dY=e(M, c.output_dim, d=torch.float32))
             cfg = _lib.AdapterConfigC(input_dim=c.input_dim, intermediate_dim=c.intermediate_dim, output_dim=c.output_dim,
                                       dropout_p=0.0, dropout_seed=0, dtype=ops.dt_of(dt))
             nbytes = call("p2t_adapter_backward_workspace_bytes", C.byref(cfg), M)
-            b["ws"] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-            b["saved"] = _lib.AdapterSavedC(z1=b["z1"].data_ptr(), h1=b["h1"].data_ptr(), z2=b["z2"].data_ptr(),
-                                            g2=b["g2"].data_ptr(), inv_norm=b["inv"].data_ptr())
-            self._buf[key] = b
+            full["ws"] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            full["saved"] = _lib.AdapterSavedC(z1=full["z1"].data_ptr(), h1=full["h1"].data_ptr(), z2=full["z2"].data_ptr(),
+                                               g2=full["g2"].data_ptr(), inv_norm=full["inv"].data_ptr())
+            self._buf = {"cap": M, "full": full}
+        full = self._buf["full"]
+        b = {k: (v[:M] if k in ("z1", "h1", "z2", "g2", "y", "inv", "dY") else v) for k, v in full.items()}
         return b
 
     def _stream(self, i: int) -> "torch.cuda.Stream":
@@ -299,8 +344,7 @@ class ContrastiveTrainer:
         pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
         tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
         B, T = pid.shape
-        nseg = self.num_segments
-        Bs = B // nseg
+        segs = self._segments(batch, B, T)
         # The text tower and the ESM2 encodes of the segments are independent until the loss: they are enqueued on
         # separate HIP streams so the tail of one kernel's grid (M = 2048 text GEMMs, 2.5-"round" encoder GEMMs)
         # is filled by another stream's blocks instead of idling CUs.  Everything joins on the caller's stream.
@@ -313,10 +357,10 @@ class ContrastiveTrainer:
                 t_local = self.text_embeddings(tid, tmask)
                 t_local.record_stream(main)
                 ev_text = torch.cuda.current_stream().record_event()
-            for s in range(nseg):
+            for s, (r0, r1, Ts, _) in enumerate(segs):
                 with torch.cuda.stream(self._stream(1 + s % 2)):
                     torch.cuda.current_stream().wait_event(start)
-                    enc = m.esm_encoder.encode(pid[s * Bs:(s + 1) * Bs], pmask[s * Bs:(s + 1) * Bs])
+                    enc = m.esm_encoder.encode(pid[r0:r1, :Ts], pmask[r0:r1, :Ts])
                     enc.record_stream(main)
                     encs.append((enc, torch.cuda.current_stream().record_event()))
             main.wait_event(ev_text)
@@ -330,9 +374,9 @@ class ContrastiveTrainer:
         wts = _lib.AdapterWeightsC(fc1_w=self.w1.data_ptr(), fc1_b=self.p[1].data_ptr(), fc2_w=self.w2.data_ptr(),
                                    fc2_b=self.p[3].data_ptr())
         mode = self.readout_fn
-        for s in range(nseg):
-            sl = slice(s * Bs, (s + 1) * Bs)
-            ids_s, mask_s = pid[sl], pmask[sl]
+        for s, (r0, r1, T, weight) in enumerate(segs):       # T: this segment's own padded length
+            sl, Bs = slice(r0, r1), r1 - r0
+            ids_s, mask_s = pid[sl, :T], pmask[sl, :T]
             if encs:
                 enc, ev = encs[s]
                 main.wait_event(ev)
@@ -350,11 +394,11 @@ class ContrastiveTrainer:
             pooled = pooled_mix if mode == "mix" else ops.readout(y3, rmask, mode, D=c.output_dim)
             p = ops.l2norm_rows(pooled)
             labels = torch.arange(sl.start + offset, sl.stop + offset, device=self.dev, dtype=torch.int32)
-            _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, 1.0 / nseg, self.loss,
+            _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, weight, self.loss,
                                             accumulate=(s > 0 or accumulate))
             if not backward:
                 continue
-            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, 1.0 / nseg)
+            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, weight)
             dpooled = ops.l2norm_rows_backward(pooled, dp)
             call("p2t_readout_backward", ptr(y3), ops.dt_of(y3), y3.stride(1), ptr(rmask.to(torch.int64).contiguous()) if rmask is not None else None,
                  Bs, T, c.output_dim, _lib.READOUT[mode], ptr(pooled_mix), ptr(dpooled), ptr(b["dY"]), stream())
@@ -366,6 +410,33 @@ class ContrastiveTrainer:
             if not self.flat_g.is_cuda:
                 self.flat_g /= dist.get_world_size(self.group)
         return self.loss
+
+    def _segments(self, batch, B: int, T: int):
+        """[(start, stop, T_s, weight)]: the row ranges of the protein side, the padded length each runs at and its
+        share of the loss.  Default: `num_segments` equal ranges at the batch's T, weight 1 / num_segments (tail rows
+        beyond num_segments * (B // num_segments) are dropped from the protein side, as upstream :339-343).
+        trim_padding: ranges from plan_length_segments over the HOST-side `protein_lengths` of the batch
+        (data.sort_batch_by_length) -- never from a device read, which would serialise host and GPU every step --
+        capped at the token count of one default segment; weight n_s / B, so the total is the mean over all rows,
+        which is what equal segments average to."""
+        nseg = self.num_segments
+        Bs = B // nseg
+        if not self.trim_padding:
+            return [(s * Bs, (s + 1) * Bs, T, 1.0 / nseg) for s in range(nseg)]
+        lengths = batch.get("protein_lengths")
+        if lengths is None:
+            raise ValueError("trim_padding=True needs batch['protein_lengths'] (host ints; data.sort_batch_by_length adds it)")
+        if torch.is_tensor(lengths):
+            if lengths.is_cuda:
+                raise ValueError("batch['protein_lengths'] must live on the host")
+            lengths = lengths.tolist()
+        if len(lengths) != B:
+            raise ValueError(f"batch['protein_lengths'] has {len(lengths)} entries for a batch of {B}")
+        if max(int(v) for v in lengths) > T:
+            raise ValueError(f"protein_lengths says {max(int(v) for v in lengths)} but the batch is only {T} wide")
+        plan = plan_length_segments(lengths, T, multiple=self.trim_multiple, max_tokens=-(-B // nseg) * T,
+                                    floor_tokens=self.trim_floor_tokens)
+        return [(a, b, Ts, (b - a) / B) for a, b, Ts in plan]
 
     def optimizer_step(self):
         """clip_grad_norm_ -> AdamW.step -> scheduler.step (train_contrast.py:453-465)."""

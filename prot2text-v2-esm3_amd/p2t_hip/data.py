@@ -12,6 +12,12 @@ What the reference does before the hot path sees a batch, restated without its d
 `ContrastiveCollater` against the reference's own `Prot2TextLightCollater` run on the same rows with the same tiny
 tokenizer (tests/golden/collate.json, written by tests/golden/make_golden.py).  `DevicePrefetcher` stages batches
 through pinned memory and a copy stream so the H2D transfer of batch i+1 overlaps the step of batch i.
+
+Ragged lengths: real proteins are much shorter than the longest of a batch.  `sort_batch_by_length` (host side, before
+the H2D copy) orders the pairs of a batch by protein length and records the lengths, so that
+`ContrastiveTrainer(num_segments=k, trim_padding=True)` can run each segment at ITS longest length instead of the
+batch's.  The in-batch InfoNCE loss does not depend on the order of the pairs, and the segmented loss of equal segments
+equals the unsegmented one (`scripts/train_contrast.py:94-114,367-379`), so the step's result is unchanged.
 """
 from __future__ import annotations
 
@@ -126,6 +132,28 @@ class ContrastiveCollater:
         return {"name": [item["AlphaFoldDB"] for item in batch], "protein_sequences": sequences,
                 "protein_input_ids": prot["input_ids"], "protein_attention_mask": prot["attention_mask"],
                 "description_input_ids": d_ids, "description_attention_mask": d_mask}
+
+
+def sort_batch_by_length(batch: Dict[str, Any], descending: bool = True) -> Dict[str, Any]:
+    """Reorder the pairs of a collated (host) batch by protein length and add `protein_lengths` (list of ints, host).
+    Every per-pair entry (tensors with leading dimension B, lists of length B) is permuted the same way."""
+    mask = batch["protein_attention_mask"]
+    if mask.is_cuda:
+        raise ValueError("sort_batch_by_length works on the host batch (before the H2D copy)")
+    lengths = mask.sum(dim=1)
+    order = torch.argsort(lengths, descending=descending, stable=True)
+    B = int(mask.shape[0])
+    idx = order.tolist()
+    out: Dict[str, Any] = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B:
+            out[k] = v[order]
+        elif isinstance(v, (list, tuple)) and len(v) == B:
+            out[k] = [v[i] for i in idx]
+        else:
+            out[k] = v
+    out["protein_lengths"] = [int(lengths[i]) for i in idx]
+    return out
 
 
 class DevicePrefetcher:

@@ -86,7 +86,7 @@ def _f32(v: torch.Tensor) -> torch.Tensor:
 
 
 class _Workspace:
-    """uint8 workspace tensors cached per key (shape-specialised, reused across calls)."""
+    """uint8 workspace tensors cached per key (the HIP stream), grow-only, reused across calls and shapes."""
 
     def __init__(self):
         self._cache = {}
@@ -198,7 +198,7 @@ class EsmEncoder(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         nbytes = call("p2t_esm2_workspace_bytes", C.byref(e["cfg"]), B, T)
-        ws = self._ws.get((B, T, torch.cuda.current_stream().cuda_stream), nbytes, dev)     # one workspace per stream
+        ws = self._ws.get(torch.cuda.current_stream().cuda_stream, nbytes, dev)     # one grow-only workspace per stream
         out = torch.empty((B, T, e["Hp"]), dtype=self.dtype, device=dev)
         call("p2t_esm2_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, ptr(out), e["Hp"],
              ptr(ws), ws.numel(), stream())
@@ -455,7 +455,7 @@ class LlamaTextModel(nn.Module):
         dev = self.embed_tokens.weight.device
         mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         nbytes = call("p2t_llama_workspace_bytes", C.byref(e["cfg"]), B, T)
-        ws = self._ws.get((B, T, torch.cuda.current_stream().cuda_stream), nbytes, dev)
+        ws = self._ws.get(torch.cuda.current_stream().cuda_stream, nbytes, dev)
         out = torch.empty((B, T, self.spec.hidden_size), dtype=torch.float32, device=dev)
         if embeds is None:
             call("p2t_llama_hidden_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(ids), ptr(mask), B, T, int(k), ptr(out),

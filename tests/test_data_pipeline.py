@@ -95,3 +95,43 @@ def test_prefetcher_keeps_order_and_content():
     assert [b["name"][0] for b in seen] == [f"n{i}" for i in range(5)]
     assert all(int(b["extra"][0, 0]) == i + 1 for i, b in enumerate(seen))
     assert list(data.DevicePrefetcher([], "cpu")) == []
+
+
+def test_sort_batch_by_length_permutes_pairs_together():
+    from p2t_hip.data import sort_batch_by_length
+    mask = torch.tensor([[1, 1, 0, 0], [1, 1, 1, 1], [1, 0, 0, 0], [1, 1, 1, 0]])
+    batch = {"name": ["a", "b", "c", "d"], "protein_input_ids": torch.arange(16).view(4, 4), "protein_attention_mask": mask,
+             "description_input_ids": torch.arange(8).view(4, 2) * 10, "description_attention_mask": torch.ones(4, 2, dtype=torch.int64),
+             "other": 7}
+    out = sort_batch_by_length(batch)
+    assert out["name"] == ["b", "d", "a", "c"] and out["protein_lengths"] == [4, 3, 2, 1] and out["other"] == 7
+    assert out["protein_input_ids"][:, 0].tolist() == [4, 12, 0, 8]
+    assert out["description_input_ids"][:, 0].tolist() == [20, 60, 0, 40]          # text rows follow their proteins
+    assert sort_batch_by_length(batch, descending=False)["name"] == ["c", "a", "d", "b"]
+    assert batch["name"] == ["a", "b", "c", "d"]                                   # input untouched
+
+
+def test_trim_padding_rejects_the_all_ones_readout():
+    from p2t_hip.contrastive import ContrastiveTrainer
+    with pytest.raises(ValueError, match="mask-aware"):
+        ContrastiveTrainer(None, ones_mask=True, trim_padding=True)
+    with pytest.raises(ValueError, match="multiple of 64"):
+        ContrastiveTrainer(None, trim_padding=True, trim_multiple=96)
+
+
+def test_plan_length_segments():
+    from p2t_hip.contrastive import plan_length_segments as plan
+    assert plan([], 128) == [] and plan([5], 1024) == [(0, 1, 128)]
+    # equal lengths: one segment unless the token cap splits it
+    assert plan([1024] * 16, 1024) == [(0, 16, 1024)]
+    assert plan([1024] * 16, 1024, max_tokens=4 * 1024) == [(0, 4, 1024), (4, 8, 1024), (8, 12, 1024), (12, 16, 1024)]
+    # a row longer than the cap still gets its own segment
+    assert plan([1000, 10], 1024, max_tokens=512, floor_tokens=0) == [(0, 1, 1024), (1, 2, 128)]
+    lens = sorted([1024, 900, 700, 500, 400, 390, 380, 300, 250, 240, 200, 130, 120, 100, 60, 30] * 4, reverse=True)
+    segs = plan(lens, 1024, multiple=128, floor_tokens=4096)
+    assert segs[0][0] == 0 and segs[-1][1] == len(lens) and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+    assert all(t % 128 == 0 and t >= max(lens[a:b]) for a, b, t in segs)
+    padded = len(lens) * 1024
+    assert sum((b - a) * t for a, b, t in segs) < 0.6 * padded              # the point of it
+    # a huge floor means splitting never pays
+    assert plan(lens, 1024, floor_tokens=10 ** 9) == [(0, len(lens), 1024)]

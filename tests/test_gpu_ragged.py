@@ -1,0 +1,80 @@
+"""Ragged batches: running each segment of a length-sorted batch at its own padded length
+(`ContrastiveTrainer(num_segments=k, trim_padding=True)` on `data.sort_batch_by_length` output) must give the loss and
+the adapter gradients of the plain step on the original batch: the in-batch InfoNCE loss is invariant to the order of
+the pairs, equal segments average to the unsegmented loss (scripts/train_contrast.py:94-114,367-379), and with the
+mask-aware readout nothing reads a padded position."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import build_model, rel, to_np
+from p2t_hip import specs, synth
+from p2t_hip.data import sort_batch_by_length
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LENGTHS = [64, 256, 17, 60, 64, 5, 33, 50]
+
+
+def _model(dtype):
+    with open(os.path.join(HERE, "golden", "train_state.json")) as f:
+        meta = json.load(f)
+    esm, llama, ad = specs.EsmSpec(**meta["esm"]), specs.LlamaSpec(**meta["llama"]), specs.AdapterSpec(**meta["adapter"])
+    return build_model(esm, llama, ad, dtype, 0), meta
+
+
+def _host_batch():
+    pid, pmask = synth.protein_batch(7, 8, 256, LENGTHS)
+    tid, tmask = synth.text_batch(7, 8, 16, 500, [16, 9, 5, 2, 12, 7, 3, 11], 510, 509)
+    return {"name": [f"P{i}" for i in range(8)], "protein_input_ids": torch.from_numpy(pid),
+            "protein_attention_mask": torch.from_numpy(pmask), "description_input_ids": torch.from_numpy(tid),
+            "description_attention_mask": torch.from_numpy(tmask)}
+
+
+def _to_dev(batch):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [(torch.float32, 2e-5, 2e-4), (torch.bfloat16, 5e-3, 5e-2)])
+def test_trimmed_segments_equal_the_padded_step(dtype, tol_loss, tol_grad):
+    import p2t_hip as P
+    model, meta = _model(dtype)
+    host = _host_batch()
+    plain = P.ContrastiveTrainer(model, output_llm_layer=meta["layer"], train_mode=False)
+    loss0 = float(to_np(plain.forward_backward(_to_dev(host)))[0])
+    g0 = to_np(plain.flat_g).copy()
+
+    srt = sort_batch_by_length(host)
+    assert srt["protein_lengths"] == sorted(LENGTHS, reverse=True) and srt["name"][0] == "P1"
+    trimmed = P.ContrastiveTrainer(model, output_llm_layer=meta["layer"], train_mode=False, num_segments=2, trim_padding=True,
+                                   trim_multiple=64, trim_floor_tokens=0)
+    segs = trimmed._segments(srt, 8, 256)
+    assert [(a, b, t) for a, b, t, _ in segs] == [(0, 1, 256), (1, 8, 64)]       # unequal ranges, own lengths
+    assert sum(w for *_, w in segs) == pytest.approx(1.0) and all((b - a) * t <= 4 * 256 for a, b, t, _ in segs)
+    loss1 = float(to_np(trimmed.forward_backward(_to_dev(srt)))[0])
+    g1 = to_np(trimmed.flat_g).copy()
+    assert abs(loss1 - loss0) <= tol_loss * max(1.0, abs(loss0))
+    assert rel(g1, g0) < tol_grad
+
+    # the same trainer on two streams (segments alternate between encode streams)
+    trimmed.overlap_streams = True
+    loss2 = float(to_np(trimmed.forward_backward(_to_dev(srt)))[0])
+    assert abs(loss2 - loss1) <= tol_loss * max(1.0, abs(loss1)) and rel(to_np(trimmed.flat_g), g1) < tol_grad
+
+
+def test_trim_padding_argument_errors():
+    import p2t_hip as P
+    model, meta = _model(torch.float32)
+    tr = P.ContrastiveTrainer(model, output_llm_layer=meta["layer"], num_segments=2, trim_padding=True)
+    dev_batch = _to_dev(_host_batch())
+    with pytest.raises(ValueError, match="protein_lengths"):
+        tr.forward_backward(dev_batch)
+    with pytest.raises(ValueError, match="host"):
+        tr.forward_backward(dict(dev_batch, protein_lengths=torch.tensor(LENGTHS).cuda()))
+    with pytest.raises(ValueError, match="entries"):
+        tr.forward_backward(dict(dev_batch, protein_lengths=LENGTHS[:4]))
+    with pytest.raises(ValueError, match="only 256 wide"):
+        tr.forward_backward(dict(dev_batch, protein_lengths=[300] * 8))
