@@ -36,6 +36,14 @@ class Esm2LlamaInstructConfig(PretrainedConfig):
     def __init__(self, esm_config: EsmConfig = None, adapter_config: ModalityAdapterConfig = None,
                  llama_config: LlamaConfig = None, placeholder_id: int = 128003, **kwargs):
         super().__init__(**kwargs)
+        # `save_pretrained` writes the sub-configs as nested dicts (PretrainedConfig.to_dict); `from_pretrained` hands
+        # them back as dicts -- rebuilt into config objects here so a saved config round-trips
+        if isinstance(esm_config, dict):
+            esm_config = EsmConfig(**{k: v for k, v in esm_config.items() if k != "model_type"})
+        if isinstance(adapter_config, dict):
+            adapter_config = ModalityAdapterConfig(**{k: v for k, v in adapter_config.items() if k != "model_type"})
+        if isinstance(llama_config, dict):
+            llama_config = LlamaConfig(**{k: v for k, v in llama_config.items() if k != "model_type"})
         self.esm_config = esm_config
         self.adapter_config = adapter_config
         self.llama_config = llama_config

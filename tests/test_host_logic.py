@@ -77,3 +77,23 @@ def test_config_surface_matches_reference_fields():
     bad.position_embedding_type = "absolute"
     with pytest.raises(ValueError, match="rotary"):
         esm_spec_from_config(bad)
+
+
+def test_assembled_config_save_pretrained_round_trip(tmp_path):
+    """HF save_pretrained / from_pretrained of Esm2LlamaInstructConfig.  PretrainedConfig writes the
+    sub-configs as nested dicts; they come back as config objects with the same tower shapes."""
+    from p2t_hip.configuration import (Esm2LlamaInstructConfig, ModalityAdapterConfig, esm_config_from_spec, esm_spec_from_config,
+                                       llama_config_from_spec, llama_spec_from_config)
+    from transformers import EsmConfig, LlamaConfig
+    esm = esm_config_from_spec(specs.esm_spec("esm2_t6_8M"))
+    llama = llama_config_from_spec(specs.llama_spec("Llama-3.2-1B"))
+    cfg = Esm2LlamaInstructConfig(esm, ModalityAdapterConfig(esm.hidden_size, 2048, llama.hidden_size, dropout_rate=0.25), llama,
+                                  placeholder_id=128003)
+    cfg.save_pretrained(tmp_path)
+    back = Esm2LlamaInstructConfig.from_pretrained(tmp_path)
+    assert isinstance(back.esm_config, EsmConfig) and isinstance(back.llama_config, LlamaConfig)
+    assert isinstance(back.adapter_config, ModalityAdapterConfig) and back.placeholder_id == 128003
+    assert esm_spec_from_config(back.esm_config) == esm_spec_from_config(esm)
+    assert llama_spec_from_config(back.llama_config) == llama_spec_from_config(llama)
+    assert back.adapter_config.to_spec() == cfg.adapter_config.to_spec()
+    assert back.model_type == "esm2llama_instruct" and back.adapter_config.model_type == "modality_adapter"
