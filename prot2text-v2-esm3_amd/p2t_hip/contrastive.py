@@ -176,10 +176,15 @@ def _gather_text(t_local: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:
 
 def teacher_forcing_forward_pass(rank, model, data_batch: Dict[str, Any], contrastive_num_segments: int, *,
                                  output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
-                                 global_negatives: bool = False, temperature: float = 0.05) -> torch.Tensor:
+                                 global_negatives: bool = False, temperature: float = 0.05,
+                                 trim_padding: bool = False, trim_multiple: int = 128) -> torch.Tensor:
     """One forward of the contrastive step (reference :313-379); the returned loss carries the autograd
     graph through the adapter.  `global_negatives=True` scores against the all-gathered global batch
-    (the reference uses per-rank negatives; with world size 1 the two coincide)."""
+    (the reference uses per-rank negatives; with world size 1 the two coincide).
+    `trim_padding=True`: each (equal) segment runs at the padded length of ITS longest protein, read from the host-side
+    `data_batch["protein_lengths"]` (data.sort_batch_by_length) -- same loss with the mask-aware readout."""
+    if trim_padding and ones_mask:
+        raise ValueError("trim_padding needs the mask-aware readout (ones_mask=False)")
     base = model.module if hasattr(model, "module") else model
     dev = next(base.adapter.parameters()).device
     pid = data_batch["protein_input_ids"].to(dev)
@@ -197,9 +202,15 @@ def teacher_forcing_forward_pass(rank, model, data_batch: Dict[str, Any], contra
         description_output, offset = _gather_text(description_output)
     loss_fn = SegmentedBatchInfoNCELoss(temperature)
     acc_loss = torch.zeros([], device=dev)
+    lengths = data_batch.get("protein_lengths") if trim_padding else None
+    if trim_padding and (lengths is None or len(lengths) != batch_size or (torch.is_tensor(lengths) and lengths.is_cuda)):
+        raise ValueError("trim_padding=True needs data_batch['protein_lengths']: one host int per pair")
     for s in range(contrastive_num_segments):
         sl = slice(s * segment_size, (s + 1) * segment_size)
-        seg = l2_normalize(get_sequence_embeddings(base, pid[sl], pmask[sl], readout_fn, ones_mask))
+        Ts = pid.shape[1]
+        if lengths is not None:
+            Ts = min(Ts, round_up(max(1, max(int(v) for v in lengths[sl])), trim_multiple))
+        seg = l2_normalize(get_sequence_embeddings(base, pid[sl, :Ts], pmask[sl, :Ts], readout_fn, ones_mask))
         labels = torch.arange(sl.start, sl.stop, device=dev) + offset
         acc_loss = acc_loss + loss_fn(segment_output1=seg, batch_output2=description_output, labels=labels)
     return acc_loss / contrastive_num_segments

@@ -65,6 +65,29 @@ def test_trimmed_segments_equal_the_padded_step(dtype, tol_loss, tol_grad):
     assert abs(loss2 - loss1) <= tol_loss * max(1.0, abs(loss1)) and rel(to_np(trimmed.flat_g), g1) < tol_grad
 
 
+def test_autograd_path_with_trimmed_segments():
+    """teacher_forcing_forward_pass(trim_padding=True): same loss and adapter gradients as the padded call."""
+    import p2t_hip as P
+    model, meta = _model(torch.float32)
+    model.eval()                                            # dropout masks depend on the row layout
+    srt = _to_dev(sort_batch_by_length(_host_batch()))
+    grads = []
+    for trim in (False, True):
+        model.adapter.zero_grad(set_to_none=True)
+        loss = P.teacher_forcing_forward_pass(0, model, srt, 4, output_llm_layer=meta["layer"], trim_padding=trim, trim_multiple=64)
+        loss.backward()
+        grads.append((float(loss.detach()), [to_np(p.grad) for p in (model.adapter.fc1.weight, model.adapter.fc1.bias,
+                                                              model.adapter.fc2.weight, model.adapter.fc2.bias)]))
+    assert abs(grads[0][0] - grads[1][0]) < 2e-5 * max(1.0, abs(grads[0][0]))
+    for a, b in zip(grads[0][1], grads[1][1]):
+        assert rel(b, a) < 2e-4
+    with pytest.raises(ValueError, match="protein_lengths"):
+        P.teacher_forcing_forward_pass(0, model, {k: v for k, v in srt.items() if k != "protein_lengths"}, 4,
+                                       output_llm_layer=meta["layer"], trim_padding=True)
+    with pytest.raises(ValueError, match="mask-aware"):
+        P.teacher_forcing_forward_pass(0, model, srt, 4, trim_padding=True, ones_mask=True)
+
+
 def test_trim_padding_argument_errors():
     import p2t_hip as P
     model, meta = _model(torch.float32)
