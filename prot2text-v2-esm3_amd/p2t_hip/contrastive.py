@@ -344,9 +344,31 @@ class ContrastiveTrainer:
             self._streams[i] = torch.cuda.Stream(device=self.dev)
         return self._streams[i]
 
-    def text_embeddings(self, tid, tmask) -> torch.Tensor:
-        hs = self.model.llama_decoder.model.hidden_state(tid, tmask, self.layer)
-        return ops.l2norm_rows(ops.readout(hs, tmask, self.readout_fn))
+    def text_embeddings(self, tid, tmask, batch: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+        """L2-normalised pooled hidden_states[layer] of the descriptions, rows in batch order.
+        trim_padding with `description_order` (device int64 [B]: rows by falling description length) and
+        `description_lengths` (host ints, batch order) in the batch -- data.sort_batch_by_length adds both -- runs the
+        text tower in that order, cut into segments at their own padded length like the protein side, and scatters
+        the pooled rows back; rows are independent in the text tower (causal attention within a row, padding masked)."""
+        order = batch.get("description_order") if (batch is not None and self.trim_padding) else None
+        lengths = batch.get("description_lengths") if order is not None else None
+        if order is None or lengths is None:
+            hs = self.model.llama_decoder.model.hidden_state(tid, tmask, self.layer)
+            return ops.l2norm_rows(ops.readout(hs, tmask, self.readout_fn))
+        B, T = tid.shape
+        if torch.is_tensor(lengths):
+            lengths = lengths.tolist()
+        if len(lengths) != B or order.numel() != B or max(int(v) for v in lengths) > T:
+            raise ValueError("description_lengths / description_order do not match the description batch")
+        by_len = sorted((int(v) for v in lengths), reverse=True)        # the lengths in `order`'s row order
+        order = order.to(device=tid.device, dtype=torch.int64)
+        ids, mask = tid.index_select(0, order), tmask.index_select(0, order)
+        D = self.model.llama_decoder.model.spec.hidden_size * (2 if self.readout_fn == "mix" else 1)
+        t_sorted = torch.empty((B, D), dtype=torch.float32, device=tid.device)
+        for a, b, Ts in plan_length_segments(by_len, T, multiple=min(self.trim_multiple, 64), floor_tokens=self.trim_floor_tokens // 2):
+            hs = self.model.llama_decoder.model.hidden_state(ids[a:b, :Ts].contiguous(), mask[a:b, :Ts].contiguous(), self.layer)
+            t_sorted[a:b] = ops.l2norm_rows(ops.readout(hs, mask[a:b, :Ts], self.readout_fn))
+        return torch.empty_like(t_sorted).index_copy_(0, order, t_sorted)
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], accumulate: bool = False, backward: bool = True) -> torch.Tensor:
         """Loss (device scalar, f32 [1]) and adapter gradients into self.g (summed over segments,
@@ -365,7 +387,7 @@ class ContrastiveTrainer:
             start = main.record_event()
             with torch.cuda.stream(self._stream(0)):
                 torch.cuda.current_stream().wait_event(start)
-                t_local = self.text_embeddings(tid, tmask)
+                t_local = self.text_embeddings(tid, tmask, batch)
                 t_local.record_stream(main)
                 ev_text = torch.cuda.current_stream().record_event()
             for s, (r0, r1, Ts, _) in enumerate(segs):
@@ -376,7 +398,7 @@ class ContrastiveTrainer:
                     encs.append((enc, torch.cuda.current_stream().record_event()))
             main.wait_event(ev_text)
         else:
-            t_local = self.text_embeddings(tid, tmask)
+            t_local = self.text_embeddings(tid, tmask, batch)
         if self.global_negatives:
             t_all, offset = _gather_text(t_local, self.group)
         else:

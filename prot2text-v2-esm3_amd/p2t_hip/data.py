@@ -135,7 +135,8 @@ class ContrastiveCollater:
 
 
 def sort_batch_by_length(batch: Dict[str, Any], descending: bool = True) -> Dict[str, Any]:
-    """Reorder the pairs of a collated (host) batch by protein length and add `protein_lengths` (list of ints, host).
+    """Reorder the pairs of a collated (host) batch by protein length and add `protein_lengths` (list of ints, host),
+    `description_lengths` (host ints) and `description_order` (int64 tensor: rows by falling description length).
     Every per-pair entry (tensors with leading dimension B, lists of length B) is permuted the same way."""
     mask = batch["protein_attention_mask"]
     if mask.is_cuda:
@@ -153,6 +154,12 @@ def sort_batch_by_length(batch: Dict[str, Any], descending: bool = True) -> Dict
         else:
             out[k] = v
     out["protein_lengths"] = [int(lengths[i]) for i in idx]
+    if "description_attention_mask" in out:
+        # the text tower may run in its own length order (rows are independent there): lengths in the new batch order
+        # (host) and the rows by falling length (a tensor, so it travels to the device with the batch)
+        dlen = out["description_attention_mask"].sum(dim=1)
+        out["description_lengths"] = [int(v) for v in dlen]
+        out["description_order"] = torch.argsort(dlen, descending=True, stable=True)
     return out
 
 

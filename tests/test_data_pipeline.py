@@ -107,6 +107,7 @@ def test_sort_batch_by_length_permutes_pairs_together():
     assert out["name"] == ["b", "d", "a", "c"] and out["protein_lengths"] == [4, 3, 2, 1] and out["other"] == 7
     assert out["protein_input_ids"][:, 0].tolist() == [4, 12, 0, 8]
     assert out["description_input_ids"][:, 0].tolist() == [20, 60, 0, 40]          # text rows follow their proteins
+    assert out["description_lengths"] == [2, 2, 2, 2] and out["description_order"].tolist() == [0, 1, 2, 3]
     assert sort_batch_by_length(batch, descending=False)["name"] == ["c", "a", "d", "b"]
     assert batch["name"] == ["a", "b", "c", "d"]                                   # input untouched
 

@@ -28,7 +28,7 @@ def _model(dtype):
 
 def _host_batch():
     pid, pmask = synth.protein_batch(7, 8, 256, LENGTHS)
-    tid, tmask = synth.text_batch(7, 8, 16, 500, [16, 9, 5, 2, 12, 7, 3, 11], 510, 509)
+    tid, tmask = synth.text_batch(7, 8, 160, 500, [160, 9, 5, 70, 12, 130, 3, 11], 510, 509)
     return {"name": [f"P{i}" for i in range(8)], "protein_input_ids": torch.from_numpy(pid),
             "protein_attention_mask": torch.from_numpy(pmask), "description_input_ids": torch.from_numpy(tid),
             "description_attention_mask": torch.from_numpy(tmask)}
@@ -54,6 +54,11 @@ def test_trimmed_segments_equal_the_padded_step(dtype, tol_loss, tol_grad):
     segs = trimmed._segments(srt, 8, 256)
     assert [(a, b, t) for a, b, t, _ in segs] == [(0, 1, 256), (1, 8, 64)]       # unequal ranges, own lengths
     assert sum(w for *_, w in segs) == pytest.approx(1.0) and all((b - a) * t <= 4 * 256 for a, b, t, _ in segs)
+    # the text side runs in its own length order (description_order), cut the same way, and is scattered back
+    assert srt["description_order"].tolist()[:3] == [srt["description_lengths"].index(v) for v in (160, 130, 70)]
+    t_plain = to_np(plain.text_embeddings(*[_to_dev(srt)[k] for k in ("description_input_ids", "description_attention_mask")]))
+    t_trim = to_np(trimmed.text_embeddings(*[_to_dev(srt)[k] for k in ("description_input_ids", "description_attention_mask")], _to_dev(srt)))
+    assert rel(t_trim, t_plain) < (1e-5 if dtype == torch.float32 else 2e-2)
     loss1 = float(to_np(trimmed.forward_backward(_to_dev(srt)))[0])
     g1 = to_np(trimmed.flat_g).copy()
     assert abs(loss1 - loss0) <= tol_loss * max(1.0, abs(loss0))
