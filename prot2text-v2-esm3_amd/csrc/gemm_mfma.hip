@@ -288,8 +288,8 @@ constexpr int vm_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 template <typename Epi>
 __global__ void __launch_bounds__(512)
     gemm_nt_mfma_persist_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M,
-                                int N, int K, int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep,
-                                SplitFix fix) {
+                                int N, int K, int tiles_m, int tiles_n, int n_items, int n_tail, int half_tail, int n_cover,
+                                EpiParams ep, SplitFix fix) {
     constexpr int MT = 8, NT = 4, WN = 4, SLOT = 512 * 64, NL = 4;
     constexpr int kEpiOps = MT * Epi::kMinOps;
     constexpr int kExtCount = NL + kEpiOps > 63 ? 63 : NL + kEpiOps;
@@ -474,11 +474,18 @@ __global__ void __launch_bounds__(512)
     // Split-K fix-up of a partial last round (see gemm_nt_mfma_tail_kernel): n_items counts the whole rounds only; each of
     // the n_tail leftover tiles runs as two K halves on two blocks -- producers on blocks [0, n_tail) (they never wait),
     // consumers on [n_tail, 2 n_tail).  All blocks of this grid are resident, so the consumer's bounded spin is safe.
+    // half_tail: the same leftover tiles, each as two 128-row halves on two blocks over the whole K (no hand-off): the
+    // partial round then costs one 128 x 256 tile (~0.62 of a tile time) instead of a whole one -- for K too short for
+    // the split-K form to pay.
     if (n_tail > 0 && (int)blockIdx.x < 2 * n_tail) {
         const int ns0 = (ns >> 1) & ~1;
         __builtin_amdgcn_s_waitcnt(vm_imm(0));                 // every DMA of the tile loop has landed before the ring is reused
         __builtin_amdgcn_s_barrier();
-        if ((int)blockIdx.x < n_tail) {
+        if (half_tail) {
+            const int t = blockIdx.x >> 1, h = blockIdx.x & 1;
+            tile_coords(n_items + t, n_items + n_tail, tiles_m, tiles_n, tm, tn);
+            gemm_tile<4, Epi>(smem, A, lda, W, ldw, M, N, 0, ns, (int64_t)tm * 256 + h * 128, tn * 256, n_cover, ep);
+        } else if ((int)blockIdx.x < n_tail) {
             const int t = blockIdx.x;
             tile_coords(n_items + t, n_items + n_tail, tiles_m, tiles_n, tm, tn);
             gemm_tile<8, Epi, TILE_PRODUCE>(smem, A, lda, W, ldw, M, N, ns0 * 32, ns - ns0, (int64_t)tm * 256, tn * 256, n_cover, ep, &fix, t);
@@ -548,7 +555,8 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
     }
     {
         // persistent kernel: shapes without edge tiles and at least one whole round of tiles.  tile: 0 / 3 = with the
-        // split-K fix-up of a partial last round when it is worth it (3: whenever possible), 4 = never
+        // split-K fix-up of a partial last round when it is worth it (3: whenever possible), 4 = never, 5 = the partial
+        // round always as 128-row halves
         const int64_t items = ceil_div(M, 256) * ceil_div(n_cover, 256);
         const int ns = K >> 5;
         // measured (profiles/r01_microbench_v4.log): whole rounds -> persistent (+5..13 %); a partial last round with
@@ -558,28 +566,35 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
         // 0.4 % of the step; with it hot in the Infinity Cache, as in the micro-benchmark, the per-tile kernel is 6 % ahead)
         const int64_t rem = items % kCUs;
         const bool eligible = items >= kCUs && (ns & 3) == 0 && ns >= 12 && M % 256 == 0 && N % 256 == 0 && n_cover == N;
-        const bool pick = tile == 3 || tile == 4 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
+        const bool pick = tile == 3 || tile == 4 || tile == 5 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
         if (eligible && pick) {
             int64_t n_full = items, n_tail = 0;
+            int half_tail = 0;
             SplitFix fix{};
             // the fix-up tiles run un-overlapped after the tile loop (~50 us): it pays when half a tile time is well above that
             // (K = 10240: +7 %), not at K = 4096 (SwiGLU GEMM of the text tower, 3.5 rounds: -7 %)
             const bool worth = tile == 3 || ns >= 192;
-            if (tile != 4 && fix_ws && rem > 0 && rem <= 128 && (ns & 7) == 0 && worth && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
+            if (tile != 4 && tile != 5 && fix_ws && rem > 0 && rem <= 128 && (ns & 7) == 0 && worth && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
                 n_full = items - rem;
                 n_tail = rem;
                 fix.flag = (unsigned*)fix_ws;
                 fix.timeout = (unsigned*)((char*)fix_ws + 1024);
                 fix.slab = (float*)((char*)fix_ws + kFixHeader);
                 fix.epoch = fix_epoch;
+            } else if ((tile == 0 || tile == 5) && rem > 0 && rem <= 128) {
+                // K too short for split-K to pay: the leftover tiles as 128-row halves, one per block (measured cold, as in
+                // a step: QKV 7.5 rounds -4.6 %, o-proj 2.5 rounds -3.7 %; FFN-down K = 10240 stays split-K: 787 vs 818 us)
+                n_full = items - rem;
+                n_tail = rem;
+                half_tail = 1;
             }
             gemm_nt_mfma_persist_kernel<Epi><<<dim3(kCUs), 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K,
                                                                       (int)ceil_div(M, 256), (int)ceil_div(n_cover, 256),
-                                                                      (int)n_full, (int)n_tail, n_cover, ep, fix);
+                                                                      (int)n_full, (int)n_tail, half_tail, n_cover, ep, fix);
             P2T_LAUNCH_CHECK();
             return P2T_OK;
         }
-        if (tile == 2 || tile == 3 || tile == 4) tile = 0;
+        if (tile == 2 || tile == 3 || tile == 4 || tile == 5) tile = 0;
     }
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);

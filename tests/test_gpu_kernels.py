@@ -334,9 +334,10 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
     assert rel(got[:, :N], plain[:, :N]) < (1e-6 if epi == EPI_RESID else 2e-3)
 
 
-@pytest.mark.parametrize("tile", ["0", "3", "4"])
+@pytest.mark.parametrize("tile", ["0", "3", "4", "5"])
 def test_gemm_persistent_forms_fuzz(ops, tile, monkeypatch):
-    """Random whole-tile shapes through the persistent kernel (default policy / split-K fix-up forced / no fix-up) against
+    """Random whole-tile shapes through the persistent kernel (default policy / split-K fix-up forced / no fix-up /
+    128-row halves for the partial round) against
     the exact fp32-FMA kernel on the same bf16 operands: any stale LDS read or mis-counted wait shows up as a wrong tile."""
     monkeypatch.setenv("P2T_GEMM_TILE", tile)
     rng = np.random.default_rng(int(tile) + 7)

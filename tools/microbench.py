@@ -75,7 +75,7 @@ def bench_cold():
         ws, ep = ops.gemm_fix_workspace(dev), [0]
         fl = 2.0 * M * N * K / 1e9
         res = []
-        for env in ("2", "4", "3", None):
+        for env in ("2", "4", "3", "5", None):
             if env is None:
                 os.environ.pop("P2T_GEMM_TILE", None)
             else:
@@ -94,7 +94,8 @@ def bench_cold():
             res.append(tot / 5)
         os.environ.pop("P2T_GEMM_TILE", None)
         print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
-              f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | default {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f}", flush=True)
+              f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | persistent+half-tiles {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f} | "
+              f"default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f}", flush=True)
 
 
 def bench_ksweep():
