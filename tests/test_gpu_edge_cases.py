@@ -50,3 +50,42 @@ def test_edge_shapes_match_oracle(golden, shape, readout):
     p = P.l2_normalize(P.get_sequence_embeddings(model, batch["protein_input_ids"], batch["protein_attention_mask"], readout))
     t = P.l2_normalize(P.get_description_embeddings(model, batch["description_input_ids"], batch["description_attention_mask"], k, readout))
     assert rel(to_np(p), ref["protein"]) < 2e-4 and rel(to_np(t), ref["text"]) < 2e-4
+
+
+@pytest.mark.parametrize("shape", SHAPES[1:], ids=lambda s: f"B{s[0]}_Tp{s[1]}_Tt{s[3]}")
+def test_edge_shapes_bf16_mfma_path(golden, shape):
+    """Same shapes through the bf16 kernels (MFMA GEMM edge tiles, flash attention with ragged tails, LDS-DMA staging of
+    rows near the end of the buffers) against the oracle with bf16 rounding at the same points."""
+    import p2t_hip as P
+    B, Tp, plens, Tt, tlens = shape
+    meta = golden("tiny")["meta"]
+    esm, llama, ad, *_ = case_setup(meta)
+    k = meta["layers"][-1]
+    pid, pmask = synth.protein_batch(41, B, Tp, plens)
+    tid, tmask = synth.text_batch(41, B, Tt, meta["id_high"], tlens, meta["pad_id"], meta["eos_id"])
+    W = model_weights(esm, llama, ad, meta["seed_w"])
+    po = O.protein_embeddings(esm, W, pid, pmask, "mix", prec=O.BF16)
+    to_ = O.text_embeddings(llama, W, tid, tmask, k, "mix", prec=O.BF16)
+    model = build_model(esm, llama, ad, torch.bfloat16, meta["seed_w"]).eval()
+    tr = P.ContrastiveTrainer(model, output_llm_layer=k, train_mode=False)
+    batch = dict(protein_input_ids=to_dev(pid), protein_attention_mask=to_dev(pmask), description_input_ids=to_dev(tid),
+                 description_attention_mask=to_dev(tmask))
+    loss = float(to_np(tr.forward_backward(batch))[0])
+    with torch.no_grad():
+        p = P.l2_normalize(P.get_sequence_embeddings(model, batch["protein_input_ids"], batch["protein_attention_mask"]))
+        t = P.l2_normalize(P.get_description_embeddings(model, batch["description_input_ids"], batch["description_attention_mask"], k))
+    assert rel(to_np(p), po) < 1e-2 and rel(to_np(t), to_) < 1e-2
+    assert abs(loss - float(O.infonce_batch(po, to_))) < 2e-2
+    # gradients: finite, unless the reference's own eps-free std readout hits 0 / 0 -- a two-token protein whose two
+    # bf16 adapter rows agree exactly in some column has variance 0 there, and d sqrt(0) is NaN upstream as well
+    # (scripts/train_contrast.py:223-235)
+    with torch.no_grad():
+        y, _ = model(protein_input_ids=batch["protein_input_ids"], protein_attention_mask=batch["protein_attention_mask"],
+                     return_adapter_outputs=True)
+    y, m = to_np(y).astype(np.float64), pmask.astype(np.float64)[:, :, None]
+    mean = (y * m).sum(1, keepdims=True) / m.sum(1, keepdims=True)
+    var = (((y - mean) ** 2) * m).sum(1) / m.sum(1)
+    finite = all(bool(torch.isfinite(g).all()) for g in tr.g)
+    assert finite or bool((var == 0).any()), "non-finite gradients without a zero-variance column"
+    if not (var == 0).any():
+        assert finite
