@@ -262,10 +262,13 @@ def main():
                     tr.step(b)
                 torch.cuda.synchronize()
                 return 64 * 2 / (time.perf_counter() - t)
-            r_pad, r_trim = rate(trainer, padded), rate(t_trim, srt)
+            r_pad, r_trim = rate(trainer, padded), rate(t_trim, srt)       # t_trim: segments on two streams (its default)
+            t_trim.overlap_streams = False
+            r_trim1 = rate(t_trim, srt)
             out["config"]["ragged_check"] = {"lengths": "64 pairs, protein lengths lognormal(5.75, 0.6) clipped to [16, T_p]",
                                              "mean_length": round(float(np.mean(lens)), 1), "longest": Tmax,
                                              "padded_samples_per_s": round(r_pad, 2), "sorted_trimmed_samples_per_s": round(r_trim, 2),
+                                             "sorted_trimmed_one_stream_samples_per_s": round(r_trim1, 2),
                                              "segments_rows_x_length": [[b - a, t] for a, b, t, _ in t_trim._segments(srt, 64, Tmax)]}
             del t_trim
         if world == 1 and not args.no_batch64_check and not args.overlap:

@@ -50,7 +50,7 @@ def test_trimmed_segments_equal_the_padded_step(dtype, tol_loss, tol_grad):
     srt = sort_batch_by_length(host)
     assert srt["protein_lengths"] == sorted(LENGTHS, reverse=True) and srt["name"][0] == "P1"
     trimmed = P.ContrastiveTrainer(model, output_llm_layer=meta["layer"], train_mode=False, num_segments=2, trim_padding=True,
-                                   trim_multiple=64, trim_floor_tokens=0)
+                                   trim_multiple=64, trim_floor_tokens=0, overlap_streams=False)
     segs = trimmed._segments(srt, 8, 256)
     assert [(a, b, t) for a, b, t, _ in segs] == [(0, 1, 256), (1, 8, 64)]       # unequal ranges, own lengths
     assert sum(w for *_, w in segs) == pytest.approx(1.0) and all((b - a) * t <= 4 * 256 for a, b, t, _ in segs)
@@ -64,7 +64,8 @@ def test_trimmed_segments_equal_the_padded_step(dtype, tol_loss, tol_grad):
     assert abs(loss1 - loss0) <= tol_loss * max(1.0, abs(loss0))
     assert rel(g1, g0) < tol_grad
 
-    # the same trainer on two streams (segments alternate between encode streams)
+    # the same trainer on two streams (segments alternate between encode streams): the default of trim_padding=True
+    assert P.ContrastiveTrainer(model, trim_padding=True).overlap_streams and not P.ContrastiveTrainer(model).overlap_streams
     trimmed.overlap_streams = True
     loss2 = float(to_np(trimmed.forward_backward(_to_dev(srt)))[0])
     assert abs(loss2 - loss1) <= tol_loss * max(1.0, abs(loss1)) and rel(to_np(trimmed.flat_g), g1) < tol_grad

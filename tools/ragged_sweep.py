@@ -46,7 +46,7 @@ def main():
     print(f"padded                      : {rate(P.ContrastiveTrainer(model), padded):7.1f} samples/s", flush=True)
     for mult in (64, 128):
         for floor in (2048, 4096, 8192, 16384, 32768):
-            tr = P.ContrastiveTrainer(model, trim_padding=True, trim_multiple=mult, trim_floor_tokens=floor)
+            tr = P.ContrastiveTrainer(model, trim_padding=True, trim_multiple=mult, trim_floor_tokens=floor, overlap_streams=False)
             segs = [(b - a, t) for a, b, t, _ in tr._segments(srt, B, Tmax)]
             r1 = rate(tr, srt)
             tr.overlap_streams = True
