@@ -349,7 +349,8 @@ class ContrastiveTrainer:
     def text_embeddings(self, tid, tmask, batch: Optional[Dict[str, Any]] = None) -> torch.Tensor:
         """L2-normalised pooled hidden_states[layer] of the descriptions, rows in batch order.
         trim_padding with `description_order` (device int64 [B]: rows by falling description length) and
-        `description_lengths` (host ints, batch order) in the batch -- data.sort_batch_by_length adds both -- runs the
+        `description_lengths` (host ints, batch order) in the batch -- data.sort_batch_by_length adds both, consistently:
+        the order must be the argsort of the lengths, which only a host copy lets this method verify -- runs the
         text tower in that order, cut into segments at their own padded length like the protein side, and scatters
         the pooled rows back; rows are independent in the text tower (causal attention within a row, padding masked)."""
         order = batch.get("description_order") if (batch is not None and self.trim_padding) else None
@@ -363,6 +364,8 @@ class ContrastiveTrainer:
         if len(lengths) != B or order.numel() != B or max(int(v) for v in lengths) > T:
             raise ValueError("description_lengths / description_order do not match the description batch")
         by_len = sorted((int(v) for v in lengths), reverse=True)        # the lengths in `order`'s row order
+        if not order.is_cuda and [int(lengths[i]) for i in order.tolist()] != by_len:   # host copy: cheap to verify
+            raise ValueError("description_order must list the rows by falling description_lengths")
         order = order.to(device=tid.device, dtype=torch.int64)
         ids, mask = tid.index_select(0, order), tmask.index_select(0, order)
         D = self.model.llama_decoder.model.spec.hidden_size * (2 if self.readout_fn == "mix" else 1)
