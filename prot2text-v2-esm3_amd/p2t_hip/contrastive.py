@@ -269,7 +269,7 @@ class ContrastiveTrainer:
                  num_segments: int = 1, output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
                  temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None,
                  overlap_streams: Optional[bool] = None, schedule=None, trim_padding: bool = False, trim_multiple: int = 128,
-                 trim_floor_tokens: int = 4096):
+                 trim_floor_tokens: int = 4096, gradient_accumulation_steps: int = 1):
         if trim_padding and ones_mask:
             raise ValueError("trim_padding needs the mask-aware readout: with ones_mask=True (the fork's quirk, "
                              "train_contrast.py:269-275) the padded positions are part of the result")
@@ -286,6 +286,9 @@ class ContrastiveTrainer:
         # towers / segments on separate HIP streams: default on for ragged segments (short segments leave CUs idle: +8 %
         # measured), off otherwise (+2.4 %, but per-kernel timings then include the co-runner -- bench.py measures without)
         self.overlap_streams, self._streams = (trim_padding if overlap_streams is None else bool(overlap_streams)), {}
+        if gradient_accumulation_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
+        self.gradient_accumulation_steps, self._micro = int(gradient_accumulation_steps), 0
         self.step_count = 0
         ad = model.adapter
         c = ad.config
@@ -375,9 +378,13 @@ class ContrastiveTrainer:
             t_sorted[a:b] = ops.l2norm_rows(ops.readout(hs, mask[a:b, :Ts], self.readout_fn))
         return torch.empty_like(t_sorted).index_copy_(0, order, t_sorted)
 
-    def forward_backward(self, batch: Dict[str, torch.Tensor], accumulate: bool = False, backward: bool = True) -> torch.Tensor:
+    def forward_backward(self, batch: Dict[str, torch.Tensor], accumulate: bool = False, backward: bool = True,
+                         grad_scale: float = 1.0, reduce: bool = True) -> torch.Tensor:
         """Loss (device scalar, f32 [1]) and adapter gradients into self.g (summed over segments,
-        all-reduce-averaged over ranks).  No host synchronisation.  backward=False stops after the loss."""
+        all-reduce-averaged over ranks).  No host synchronisation.  backward=False stops after the loss.
+        accumulate: add the gradients to self.g instead of overwriting (the loss is always this batch's own);
+        grad_scale: factor on the gradients only (1 / gradient_accumulation_steps: `loss / GA` before `backward()`,
+        train_contrast.py:428-448); reduce=False leaves the cross-rank average to a later call (sums commute with it)."""
         m, c = self.model, self.c
         pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
         tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
@@ -432,18 +439,17 @@ class ContrastiveTrainer:
             pooled = pooled_mix if mode == "mix" else ops.readout(y3, rmask, mode, D=c.output_dim)
             p = ops.l2norm_rows(pooled)
             labels = torch.arange(sl.start + offset, sl.stop + offset, device=self.dev, dtype=torch.int32)
-            _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, weight, self.loss,
-                                            accumulate=(s > 0 or accumulate))
+            _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, weight, self.loss, accumulate=s > 0)
             if not backward:
                 continue
-            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, weight)
+            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, weight * grad_scale)
             dpooled = ops.l2norm_rows_backward(pooled, dp)
             call("p2t_readout_backward", ptr(y3), ops.dt_of(y3), y3.stride(1), ptr(rmask.to(torch.int64).contiguous()) if rmask is not None else None,
                  Bs, T, c.output_dim, _lib.READOUT[mode], ptr(pooled_mix), ptr(dpooled), ptr(b["dY"]), stream())
             call("p2t_adapter_backward", C.byref(cfg), C.byref(wts), ptr(enc), Hp, M, C.byref(b["saved"]), ptr(b["dY"]),
                  ptr(self.g[0]), ptr(self.g[1]), ptr(self.g[2]), ptr(self.g[3]), int(s > 0 or accumulate), ptr(b["ws"]),
                  b["ws"].numel(), stream())
-        if backward and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if backward and reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG if self.flat_g.is_cuda else dist.ReduceOp.SUM, group=self.group)
             if not self.flat_g.is_cuda:
                 self.flat_g /= dist.get_world_size(self.group)
@@ -489,8 +495,15 @@ class ContrastiveTrainer:
         return self.grad_norm
 
     def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        loss = self.forward_backward(batch)
-        self.optimizer_step()
+        """One micro-batch of `train_epoch` (train_contrast.py:417-465): gradients of loss / GA are accumulated, and every
+        `gradient_accumulation_steps` calls clip + AdamW + scheduler run.  Returns this batch's (unscaled) loss."""
+        ga = self.gradient_accumulation_steps
+        last = self._micro == ga - 1
+        loss = self.forward_backward(batch, accumulate=self._micro > 0, grad_scale=1.0 / ga, reduce=last)
+        self._micro += 1
+        if last:
+            self.optimizer_step()
+            self._micro = 0
         return loss
 
     @torch.no_grad()

@@ -131,3 +131,40 @@ def test_device_prefetcher_on_gpu_feeds_the_trainer():
         got.append(float(to_np(tr.step(b))[0]))
     assert names == ["b0", "b1", "b2", "b3"]
     assert got == pytest.approx(meta["losses"], rel=2e-4)
+
+
+def test_gradient_accumulation_matches_reference_loop_semantics():
+    """train_contrast.py:428-465: each micro-batch back-propagates loss / GA into the same gradient buffers; clip + AdamW +
+    scheduler run once per GA micro-batches; the logged loss is the micro-batch's own."""
+    import p2t_hip as P
+    meta = _meta()
+    esm, llama, ad = (specs.EsmSpec(**meta["esm"]), specs.LlamaSpec(**meta["llama"]), specs.AdapterSpec(**meta["adapter"]))
+    model = build_model(esm, llama, ad, torch.float32, 0)
+    b0, b1 = _batch(meta, 0), _batch(meta, 1)
+    one = P.ContrastiveTrainer(model, lr=meta["lr"], output_llm_layer=meta["layer"], train_mode=False)
+    l0 = float(to_np(one.forward_backward(b0))[0]); g0 = to_np(one.flat_g).copy()
+    l1 = float(to_np(one.forward_backward(b1))[0]); g1 = to_np(one.flat_g).copy()
+    p_before = to_np(one.flat_p).copy()
+
+    sched = ts.CosineWarmupSchedule(meta["lr"], 0, 10)
+    ga = P.ContrastiveTrainer(model, lr=meta["lr"], output_llm_layer=meta["layer"], train_mode=False, schedule=sched,
+                              gradient_accumulation_steps=2)
+    assert float(to_np(ga.step(b0))[0]) == pytest.approx(l0, rel=1e-6)
+    assert ga.step_count == 0 and sched.last_epoch == 0 and np.array_equal(to_np(ga.flat_p), p_before)    # no update yet
+    assert rel(to_np(ga.flat_g), 0.5 * g0) < 1e-6
+    assert float(to_np(ga.step(b1))[0]) == pytest.approx(l1, rel=1e-6)                                   # own loss, not a sum
+    assert ga.step_count == 1 and sched.last_epoch == 1
+    assert rel(to_np(ga.flat_g), 0.5 * (g0 + g1)) < 1e-5
+    # the update equals one AdamW step (torch) on the averaged gradients
+    ref_p = torch.nn.Parameter(torch.from_numpy(p_before.copy()))
+    opt = torch.optim.AdamW([ref_p], lr=meta["lr"], eps=1e-6, betas=(0.9, 0.999))
+    ref_p.grad = torch.from_numpy(0.5 * (g0 + g1))
+    opt.step()
+    assert rel(to_np(ga.flat_p), ref_p.detach().numpy()) < 1e-6
+    # third micro-batch starts a fresh accumulation
+    g_acc = to_np(ga.flat_g).copy()
+    ga.step(b0)
+    assert ga.step_count == 1 and ga._micro == 1
+    assert rel(to_np(ga.flat_g), g_acc) > 0.1 and np.linalg.norm(to_np(ga.flat_g)) < 0.8 * np.linalg.norm(g0)   # overwritten, half weight
+    with pytest.raises(ValueError):
+        P.ContrastiveTrainer(model, gradient_accumulation_steps=0)
