@@ -134,6 +134,36 @@ def bench_norm():
         print(f"layernorm {rows}x{cols}: {ms * 1e3:7.1f} us  {rows * cols * 6 / ms / 1e6:7.1f} GB/s", flush=True)
 
 
+def bench_blas():
+    """Vendor-library reference point (NOT used by the product): torch.matmul (hipBLASLt / rocBLAS) on the encoder GEMM
+    shapes, plain bf16 store, same cold-cache protocol as `cold`."""
+    shapes = [("esm qkv", 16384, 7680, 2560), ("esm o", 16384, 2560, 2560), ("esm fc1", 16384, 10240, 2560),
+              ("esm fc2", 16384, 2560, 10240), ("square", 8192, 8192, 8192)]
+    flush = torch.empty((768 << 20,), dtype=torch.uint8, device=dev)
+    for name, M, N, K in shapes:
+        a, w = rand((M, K)), rand((N, K), scale=0.05)
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        fl = 2.0 * M * N * K / 1e9
+        res = []
+        for which in ("blas", "ours"):
+            tot = 0.0
+            for i in range(6):
+                flush.fill_(i)
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                if which == "blas":
+                    torch.matmul(a, w.t(), out=out)
+                else:
+                    ops.gemm_nt(a, w, None, epilogue=0, out=out, use_mfma=1)
+                e0.record()
+                torch.cuda.synchronize()
+                if i > 0:
+                    tot += s0.elapsed_time(e0)
+            res.append(tot / 5)
+        print(f"blas {name:8s} M={M} N={N} K={K}: torch.matmul {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | p2t gemm_nt (store epilogue) "
+              f"{res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "norm"]
     print(torch.cuda.get_device_name(0), flush=True)
@@ -147,3 +177,5 @@ if __name__ == "__main__":
         bench_attn()
     if "norm" in which:
         bench_norm()
+    if "blas" in which:
+        bench_blas()
