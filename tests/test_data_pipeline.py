@@ -136,3 +136,27 @@ def test_plan_length_segments():
     assert sum((b - a) * t for a, b, t in segs) < 0.6 * padded              # the point of it
     # a huge floor means splitting never pays
     assert plan(lens, 1024, floor_tokens=10 ** 9) == [(0, len(lens), 1024)]
+
+
+def test_prefetcher_with_length_sort_transform_keeps_host_lengths():
+    """DevicePrefetcher(transform=sort_batch_by_length): tensors move, `protein_lengths` / `description_lengths` stay
+    host lists, `description_order` travels as a tensor; every batch of the loader comes out once, in order."""
+    from p2t_hip.data import DevicePrefetcher, sort_batch_by_length
+
+    def make(i):
+        mask = torch.zeros(3, 6, dtype=torch.int64)
+        for r, n in enumerate([2 + i, 6, 3]):
+            mask[r, :n] = 1
+        return {"name": [f"b{i}r{r}" for r in range(3)], "protein_input_ids": torch.arange(18).view(3, 6) + 100 * i,
+                "protein_attention_mask": mask, "description_input_ids": torch.arange(12).view(3, 4),
+                "description_attention_mask": torch.tensor([[1, 1, 0, 0], [1, 1, 1, 1], [1, 0, 0, 0]])}
+
+    out = list(DevicePrefetcher([make(0), make(1), make(2)], "cpu", transform=sort_batch_by_length))
+    assert [b["name"][0] for b in out] == ["b0r1", "b1r1", "b2r1"] and len(out) == 3
+    for i, b in enumerate(out):
+        assert b["protein_lengths"] == sorted([2 + i, 6, 3], reverse=True) and isinstance(b["protein_lengths"], list)
+        assert b["protein_attention_mask"].sum(1).tolist() == b["protein_lengths"]
+        assert isinstance(b["description_lengths"], list) and torch.is_tensor(b["description_order"])
+        lens = b["description_lengths"]
+        assert [lens[j] for j in b["description_order"].tolist()] == sorted(lens, reverse=True)
+    assert list(DevicePrefetcher([], "cpu")) == []
