@@ -107,3 +107,21 @@ def test_trim_padding_argument_errors():
         tr.forward_backward(dict(dev_batch, protein_lengths=LENGTHS[:4]))
     with pytest.raises(ValueError, match="only 256 wide"):
         tr.forward_backward(dict(dev_batch, protein_lengths=[300] * 8))
+
+
+def test_prefetcher_sort_transform_feeds_the_trimming_trainer():
+    """Host batches -> DevicePrefetcher(transform=sort_batch_by_length) -> ContrastiveTrainer(trim_padding=True): the order
+    tensor arrives on the device with the batch, the length lists stay on the host, and each step's loss equals the plain
+    padded step on the same (unsorted) host batch."""
+    import p2t_hip as P
+    model, meta = _model(torch.float32)
+    hosts = [_host_batch(), {k: (v.flip(0) if torch.is_tensor(v) else v[::-1]) for k, v in _host_batch().items()}]
+    plain = P.ContrastiveTrainer(model, output_llm_layer=meta["layer"], train_mode=False)
+    want = [float(to_np(plain.forward_backward(_to_dev(h)))[0]) for h in hosts]
+    trim = P.ContrastiveTrainer(model, output_llm_layer=meta["layer"], train_mode=False, trim_padding=True, trim_multiple=64,
+                                trim_floor_tokens=0)
+    got = []
+    for batch in P.DevicePrefetcher(hosts, "cuda:0", transform=sort_batch_by_length):
+        assert batch["description_order"].is_cuda and isinstance(batch["protein_lengths"], list)
+        got.append(float(to_np(trim.forward_backward(batch))[0]))
+    assert got == pytest.approx(want, rel=2e-5) and want[0] == pytest.approx(want[1], rel=1e-5)     # order of pairs is irrelevant
