@@ -86,6 +86,17 @@ int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
                 void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
                 int use_mfma, void* fix_ws, size_t fix_ws_bytes, unsigned fix_epoch, p2t_stream stream);
 size_t p2t_gemm_fix_workspace_bytes(void);
+/* The QKV projection as the towers launch it for head_dim 64 / 128 (P2T_EPI_QKV_ROPE): acc + bias, query * q_scale
+ * BEFORE the rotation (HF EsmSelfAttention.forward, modeling_esm.py:345,362-378: q_scale = head_dim^-1/2 and SDPA scale 1;
+ * Llama: q_scale 1, no bias, modeling_llama.py:254-259), rotate-half rotary with the table built from inv_freq
+ * (f32 [head_dim/2]; cos_sin_scratch f32 [seq * head_dim]), head split.  A `dtype` [M = B * seq, lda]; W `dtype`
+ * [(nh + 2 nkv) * head_dim, ldw], rows q heads | k heads | v heads, for head_dim 128 in the packed per-head row order of
+ * p2t_llama_layer; bias f32 or NULL.  Outputs `dtype`: q [B, nh, seq, head_dim], k and v [B, nkv, seq, head_dim].
+ * Exposed so that the fused epilogue can be checked on its own against the reference arithmetic. */
+int p2t_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t K,
+                      int dtype, const float* inv_freq, float* cos_sin_scratch, void* q, void* k, void* v, int seq, int nh,
+                      int nkv, int head_dim, float q_scale, int use_mfma, void* fix_ws, size_t fix_ws_bytes,
+                      unsigned fix_epoch, p2t_stream stream);
 
 /* torch.nn.LayerNorm over the last dim: x f32 [rows, ld_x] -> y `out_dtype` [rows, ld_y]; pad zeroed. */
 int p2t_layernorm(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* y, int64_t ld_y,

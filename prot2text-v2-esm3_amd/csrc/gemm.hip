@@ -135,6 +135,20 @@ extern "C" int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
 
 extern "C" size_t p2t_gemm_fix_workspace_bytes(void) { return gemm_fix_workspace_bytes(); }
 
+extern "C" int p2t_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t K,
+                                 int dtype, const float* inv_freq, float* cos_sin_scratch, void* q, void* k, void* v, int seq,
+                                 int nh, int nkv, int head_dim, float q_scale, int use_mfma, void* fix_ws, size_t fix_ws_bytes,
+                                 unsigned fix_epoch, p2t_stream stream) {
+    P2T_REQUIRE(inv_freq && cos_sin_scratch && seq > 0 && nh > 0 && nkv > 0, "p2t_gemm_qkv_rope: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    P2T_TRY(launch_rope_table(inv_freq, seq, head_dim / 2, cos_sin_scratch, s));
+    GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, nullptr, M, (int64_t)(nh + 2 * nkv) * head_dim, K, dtype, dtype, P2T_EPI_QKV_ROPE,
+               0, use_mfma, -1, 0.f, 0, 0};
+    a.cs = cos_sin_scratch; a.q = q; a.k = k; a.v = v; a.seq = seq; a.nh = nh; a.nkv = nkv; a.q_scale = q_scale; a.head_dim = head_dim;
+    a.fix_ws = fix_ws; a.fix_bytes = fix_ws_bytes; a.fix_epoch = fix_epoch;
+    return gemm_nt(a, s);
+}
+
 extern "C" int p2t_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
                                 uint8_t* key_mask, int32_t* kv_info, float* emb_scale, p2t_stream stream) {
     P2T_REQUIRE(mask && key_mask && kv_info && B > 0 && T > 0, "p2t_mask_prepare: bad arguments");

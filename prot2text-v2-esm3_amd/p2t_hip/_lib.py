@@ -91,6 +91,8 @@ SIGNATURES = {
     "p2t_transpose": (i32, [vp, i64, i64, i64, vp, i64, i32, vp]),
     "p2t_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32, vp, sz, C.c_uint, vp]),
     "p2t_gemm_fix_workspace_bytes": (sz, []),
+    "p2t_gemm_qkv_rope": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, sz,
+                                C.c_uint, vp]),
     "p2t_layernorm": (i32, [vp, i64, vp, vp, f32, vp, i64, i64, i64, i32, vp]),
     "p2t_rmsnorm": (i32, [vp, i64, vp, f32, vp, i64, i64, i64, i32, vp]),
     "p2t_mask_prepare": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),

@@ -93,6 +93,24 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
     return out
 
 
+def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, inv_freq: torch.Tensor, seq: int, nh: int,
+                  nkv: int, head_dim: int, q_scale: float, *, k: int | None = None, use_mfma: int = -1,
+                  fix_ws: torch.Tensor | None = None, fix_epoch: int = 0):
+    """The towers' fused QKV projection (bias + query scale + rotary + head split) on its own:
+    a [B * seq, lda] @ w [(nh + 2 nkv) * head_dim, ldw]^T -> q [B, nh, seq, d], k, v [B, nkv, seq, d]."""
+    _chk(a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype, "gemm_qkv_rope: operands")
+    _chk(head_dim in (64, 128) and w.shape[0] == (nh + 2 * nkv) * head_dim and a.shape[0] % seq == 0, "gemm_qkv_rope: shapes")
+    M, B = a.shape[0], a.shape[0] // seq
+    k = min(a.shape[1], w.shape[1]) if k is None else k
+    e = lambda h: torch.empty((B, h, seq, head_dim), dtype=a.dtype, device=a.device)
+    q, kk, v = e(nh), e(nkv), e(nkv)
+    cs = torch.empty((seq, head_dim), dtype=torch.float32, device=a.device)
+    call("p2t_gemm_qkv_rope", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, k, dt_of(a), ptr(inv_freq.float().contiguous()),
+         ptr(cs), ptr(q), ptr(kk), ptr(v), seq, nh, nkv, head_dim, float(q_scale), use_mfma, ptr(fix_ws),
+         fix_ws.numel() if fix_ws is not None else 0, int(fix_epoch), stream())
+    return q, kk, v
+
+
 def positions_where(values: torch.Tensor, match: int | None = None):
     """Flat positions (int32, array order) of `values == match` (or `values != 0` when match is None) and their count
     (int32 [1]), both on the device: the enumeration order of torch's boolean-mask indexing."""

@@ -401,7 +401,7 @@ def run_sft(ref):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,cfg1,collate,train_state,sft")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,cfg1,collate,train_state,sft")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -436,6 +436,16 @@ def main():
                                 num_key_value_heads=1, vocab_size=300)
         ad = specs.AdapterSpec(64, 80, 256, 0.3)
         run_case(ref, "tiny_d128", esm, llama, ad, B=4, T_p=24, T_t=40, p_lens=[24, 15, 7, 3], t_lens=[40, 33, 9, 2],
+                 layers=[1, 2], id_high=290, pad_id=299, eos_id=298)
+    if "tiny_d64" in only:
+        # ENCODER with head_dim 64 (esm2_t33_650M / esm2_t36_3B's): the towers take the fused QKV epilogue with bias +
+        # q * d^-1/2 BEFORE the rotation + rotate-half + head split (HF modeling_esm.py:345,362-378) -- the path bench.py
+        # times.  Text tower head_dim 64 with GQA 2:1 (Llama-3.2-1B's), llama3 rope.
+        esm = specs.EsmSpec(num_hidden_layers=3, hidden_size=128, intermediate_size=320, num_attention_heads=2)
+        llama = specs.LlamaSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=192, num_attention_heads=2,
+                                num_key_value_heads=1, vocab_size=300)
+        ad = specs.AdapterSpec(128, 96, 128, 0.3)
+        run_case(ref, "tiny_d64", esm, llama, ad, B=5, T_p=70, T_t=24, p_lens=[70, 64, 33, 9, 3], t_lens=[24, 17, 8, 2, 1],
                  layers=[1, 2], id_high=290, pad_id=299, eos_id=298)
     if "cfg1" in only:
         name_e, name_l, _, B, T_p, T_t = specs.CONFIGS["cfg1"]

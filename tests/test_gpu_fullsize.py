@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import build_model, dev, rel, to_dev, to_np
+from gpu_util import build_model, dev, observe, rel, to_dev, to_np
 from p2t_hip import specs, synth
 
 pytestmark = pytest.mark.gpu
@@ -52,9 +52,14 @@ def test_cfg2_full_models_vs_cpu_oracle():
         t = P.l2_normalize(P.get_description_embeddings(model, b["description_input_ids"], b["description_attention_mask"], layer))
         loss = float(P.BatchInfoNCELoss()(p, t))
     ref = O.contrastive_step(esm, llama, GpuWeights(model), pid, pmask, tid, tmask, layer=layer, num_segments=1, prec=O.BF16)
-    assert rel(to_np(t), ref["text"]) < 2e-2
-    assert rel(to_np(p), ref["protein"]) < 2e-2
-    assert abs(loss - float(ref["loss"])) < 2e-2 * max(1.0, abs(float(ref["loss"])))
+    observe("cfg2.bf16_vs_bf16oracle.text", rel(to_np(t), ref["text"]), 2e-2)
+    observe("cfg2.bf16_vs_bf16oracle.protein", rel(to_np(p), ref["protein"]), 2e-2)
+    observe("cfg2.bf16_vs_bf16oracle.loss", abs(loss - float(ref["loss"])) / max(1.0, abs(float(ref["loss"]))), 2e-2, "abs/max(1,|ref|)")
+    # the same slice against the fp32 oracle (= the reference's CPU arithmetic): the bf16-vs-reference figure BASELINE.md quotes
+    ref32 = O.contrastive_step(esm, llama, GpuWeights(model), pid, pmask, tid, tmask, layer=layer, num_segments=1)
+    observe("cfg2.bf16_vs_fp32oracle.text", rel(to_np(t), ref32["text"]), 3e-2)
+    observe("cfg2.bf16_vs_fp32oracle.protein", rel(to_np(p), ref32["protein"]), 3e-2)
+    observe("cfg2.bf16_vs_fp32oracle.loss", abs(loss - float(ref32["loss"])) / max(1.0, abs(float(ref32["loss"]))), 3e-2, "abs/max(1,|ref|)")
 
 
 @pytest.fixture(scope="module")
@@ -126,8 +131,8 @@ def test_cfg3_bf16_pipeline_vs_exact_fp32_pipeline(cfg3):
     p32, t32 = _embeddings(P, m32, b)
     del m32
     torch.cuda.empty_cache()
-    assert rel(t16, t32) < 3e-2
-    assert rel(p16, p32) < 5e-2                                                  # 36 layers of bf16 storage
+    observe("cfg3.bf16_vs_fp32pipeline.text", rel(t16, t32), 3e-2)
+    observe("cfg3.bf16_vs_fp32pipeline.protein", rel(p16, p32), 5e-2)             # 36 layers of bf16 storage
 
 
 def test_cfg3_batch_size_invariance_across_kernel_forms(cfg3):
@@ -172,6 +177,7 @@ def test_cfg3_ragged_batch_trimmed_segments_equal_padded_step(cfg3):
     assert len(segs) >= 2 and sum((b - a) * t for a, b, t, _ in segs) < 0.8 * B * Tmax
     l1 = float(to_np(trim.forward_backward(srt))[0])
     g1 = to_np(trim.flat_g).copy()
-    assert np.isfinite(l0) and abs(l1 - l0) < 2e-2 * max(1.0, abs(l0))
-    assert rel(g1, g0) < 6e-2
+    assert np.isfinite(l0)
+    observe("cfg3.ragged_trim_vs_padded.loss", abs(l1 - l0) / max(1.0, abs(l0)), 2e-2, "abs/max(1,|ref|)")
+    observe("cfg3.ragged_trim_vs_padded.grads", rel(g1, g0), 6e-2)
     torch.cuda.empty_cache()

@@ -19,7 +19,7 @@ def test_ops_readout_and_losses(golden):
     assert abs(O.infonce_segmented(g["p"][3:6], g["t"], np.array([3, 4, 5])) - g["loss_seg"]) < 1e-5
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
 def test_towers_and_step(golden, case):
     g = golden(case)
     meta = g["meta"]
@@ -57,7 +57,7 @@ def test_towers_and_step(golden, case):
             assert rel_err(out["grads"]["adapter." + n], g[f"grad_seg{nseg}_{n}"]) < 1e-4, n
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
 def test_clip_adamw_step(golden, case):
     g = golden(case)
     meta = g["meta"]
