@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: contrastive-step samples/s (protein-text pairs) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_*) this process IS one rank; without one, this process only starts the N ranks as fresh child processes -- it never
+touches the GPU itself -- relays rank 0's JSON line and exits non-zero if any rank does (the reference does the same with
+mp.spawn, scripts/train_contrast.py:706-718).
 
 A step = one pass of the hot path over one synthetic batch, inputs resident in HBM: frozen text
 tower (Llama layers 1..16) -> frozen ESM2 encoder -> adapter forward -> readout / normalise ->
@@ -125,19 +130,70 @@ def pmc_traffic(cfg_name, batch):
         return None
 
 
+def spawn_ranks(n: int) -> int:
+    """Start `n` ranks of this script (same argv) as child processes with the torch.distributed environment set, before
+    anything in THIS process has touched the GPU (no torch import here).  Rank 0's stdout is relayed line by line; the
+    first failing rank ends the run (the others are terminated) and its exit code is returned."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), P2T_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL peer access on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc = 0
+    alive = set(range(n))
+    while alive and rc == 0:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+        time.sleep(0.2)
+    for r in alive:                                   # a rank failed: the others would wait in a collective forever
+        procs[r].terminate()
+    for pr in procs:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    t.join(timeout=5)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
-    import p2t_hip as P
-    from p2t_hip import _lib, specs, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    n_dev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if local >= n_dev:
+        raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} needs {args.gpus} GPUs on this node, it exposes {n_dev} "
+                         f"(one process per GPU; there is no CPU or shared-GPU fallback)")
+    import p2t_hip as P
+    from p2t_hip import _lib, specs, synth
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
@@ -207,7 +263,10 @@ def main():
             "config": {"workload": f"{args.config}: {esm_name} + {llama_name} (text layers 1-16), per-GPU batch {B} x {Tp} residues / "
                                    f"{B} x {Tt} text tokens, readout mix, InfoNCE tau=0.05, adapter fwd+bwd + clip + AdamW, "
                                    f"{'train mode (dropout 0.3)' if not args.eval_mode else 'eval mode'}, segments {args.segments}",
-                       "global_batch": world * B, "parallelism": f"dp{world} (text-embedding all-gather + adapter-grad all-reduce over RCCL)",
+                       "global_batch": world * B,
+                       "parallelism": (f"dp{dist.get_world_size()} over {dist.get_backend()} (RCCL): {dist.get_world_size()} processes, one GPU each; "
+                                       "text-embedding all-gather + one adapter-gradient all-reduce per step") if world > 1
+                                      else "dp1 (single process, no collective)",
                        "algorithmic_tflop_per_sample": round(f["total"] / 1e12, 4),
                        "step_tflops_per_gpu": round(step_tflops, 1), "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                        "loss": round(loss_val, 5)},

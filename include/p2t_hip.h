@@ -273,6 +273,21 @@ int p2t_infonce_forward(const float* seg, const float* batch, const int32_t* lab
 int p2t_infonce_backward(const float* batch, const int32_t* labels, const float* logits, int S, int N, int D,
                          float temperature, float weight, float* d_seg, p2t_stream stream);
 
+/* Optional column (text -> protein) term -- not in the reference loop, which is row-only (train_contrast.py:94-114);
+ * its arithmetic is the reference's own BatchInfoNCELoss with the arguments swapped (:72-91), i.e.
+ * F.cross_entropy(logits^T, arange).  p_all, t_all: f32 [N, D], the L2-normalised protein / text embeddings of the GLOBAL
+ * batch (all-gathered), positives on the diagonal.  col_lse[j] = logsumexp_i(l_ij) for every column j (output, f32 [N]);
+ * loss_out[0] (+)= weight * mean of (col_lse_j - l_jj) over `count` columns: j = cols[i] (i32 [count], device) when cols is
+ * given, else j = first .. first+count-1 (this rank's / this segment's own columns).
+ * scratch_logits f32 [N, N], scratch_col_loss f32 [N]. */
+int p2t_infonce_col_forward(const float* p_all, const float* t_all, int N, int D, float temperature, const int32_t* cols,
+                            int first, int count, float weight, int accumulate, float* loss_out, float* col_lse,
+                            float* scratch_logits, float* scratch_col_loss, p2t_stream stream);
+/* Gradient of sum_j (col_lse_j - l_jj) with respect to the S protein rows whose row logits [S, N] the row forward wrote:
+ * d_seg[i] (+)= scale / temperature * sum_j (exp(l_ij - col_lse_j) - [j == labels_i]) t_all[j]. */
+int p2t_infonce_col_backward(const float* t_all, const int32_t* labels, const float* logits, const float* col_lse, int S,
+                             int N, int D, float temperature, float scale, int accumulate, float* d_seg, p2t_stream stream);
+
 /* ---------------------------------------------------------------- optimizer tail */
 /* One clip_grad_norm_(max_norm) + AdamW step over n_tensors (<= 64) f32 parameter tensors (HOST arrays of
  * device pointers).  shadow[i] (optional, may be NULL per tensor) receives the updated parameter in

@@ -391,6 +391,26 @@ def infonce_batch(out1, out2, temperature: float = 0.05):
     return infonce_segmented(out1, out2, np.arange(out1.shape[0]), temperature)
 
 
+def infonce_columns(p_all, t_all, cols=None, temperature: float = 0.05, return_grad=False):
+    """Column (text -> protein) term: the reference's BatchInfoNCELoss with its two arguments swapped
+    (REF scripts/train_contrast.py:72-91 called as loss(text, protein)), i.e. F.cross_entropy(logits.T, arange):
+    mean over the columns j in `cols` (default all) of logsumexp_i(l_ij) - l_jj, l = P T^T / tau, positives on the diagonal.
+    return_grad: also d(sum_j (lse_j - l_jj)) / dP [N, D] over ALL columns (the caller scales by 1 / N), the gradient the
+    protein side receives from the column term of the whole batch (the text side is frozen, :348-354)."""
+    p = p_all.astype(F32); t = t_all.astype(F32)
+    logits = (p @ t.T) / F32(temperature)                      # [i, j]
+    e = np.exp(logits, dtype=F32)
+    den = e.sum(0, dtype=F32)                                   # per column j, over proteins i
+    col = (np.log(den, dtype=F32) - np.diag(logits)).astype(F32)
+    cols = np.arange(p.shape[0]) if cols is None else np.asarray(cols)
+    loss = F32(col[cols].mean(dtype=F32))
+    if not return_grad:
+        return loss
+    sm = e / den[None, :]
+    sm[np.arange(p.shape[0]), np.arange(p.shape[0])] -= F32(1.0)
+    return loss, ((sm @ t) / F32(temperature)).astype(F32)
+
+
 def l2_normalize_backward(x, dy, eps=1e-12):
     n = np.maximum(np.sqrt((x * x).sum(-1, keepdims=True, dtype=F32)), F32(eps))
     y = x / n
@@ -435,13 +455,17 @@ def contrastive_loss(p_norm, t_norm, num_segments: int = 1, temperature: float =
 
 def contrastive_step(esm_spec, llama_spec, W, prot_ids, prot_mask, text_ids, text_mask, *,
                      layer=16, readout="mix", ones_mask=False, num_segments=1, temperature=0.05,
-                     prec: Precision = FP32, with_grads=False):
+                     prec: Precision = FP32, with_grads=False, column_weight=0.0):
     """Forward (+ adapter gradients) of one contrastive step.  Returns a dict with the normalised
-    pooled embeddings, the loss and, if requested, d loss / d adapter.{fc1,fc2}.{weight,bias}."""
+    pooled embeddings, the loss and, if requested, d loss / d adapter.{fc1,fc2}.{weight,bias}.
+    column_weight = cw > 0 (not in the reference loop): loss = (1 - cw) * row term + cw * column term."""
     keep = {} if with_grads else None
+    cw = F32(column_weight)
     t = text_embeddings(llama_spec, W, text_ids, text_mask, layer, readout, prec)
     p = protein_embeddings(esm_spec, W, prot_ids, prot_mask, readout, ones_mask, prec, keep)
     out = {"protein": p, "text": t, "loss": contrastive_loss(p, t, num_segments, temperature)}
+    if column_weight > 0:
+        out["loss"] = F32((F32(1.0) - cw) * out["loss"] + cw * infonce_columns(p, t, None, temperature))
     if with_grads:
         B = p.shape[0]
         seg = B // num_segments
@@ -450,6 +474,9 @@ def contrastive_step(esm_spec, llama_spec, W, prot_ids, prot_mask, text_ids, tex
             labels = np.arange(s * seg, (s + 1) * seg)
             _, g, _ = infonce_segmented(p[s * seg:(s + 1) * seg], t, labels, temperature, return_grad=True)
             dp[s * seg:(s + 1) * seg] = g / F32(num_segments)
+        if column_weight > 0:
+            _, gcol = infonce_columns(p, t, None, temperature, return_grad=True)
+            dp = (F32(1.0) - cw) * dp + cw * gcol / F32(B)
         dpooled = l2_normalize_backward(keep["pooled"], dp)
         dad = readout_backward(keep["adapter_out"], keep["rmask"], readout, dpooled)
         out["grads"] = adapter_backward(W, keep, dad, prec, prefix="adapter.")

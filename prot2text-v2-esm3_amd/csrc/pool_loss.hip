@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(256) readout_bwd_kernel(const T* __restrict__ 
 // without the shift; |l| <= 1/tau = 20, identical up to fp32 rounding).
 __global__ void __launch_bounds__(256) infonce_fwd_kernel(const float* __restrict__ seg, const float* __restrict__ batch,
                                                           const int32_t* __restrict__ labels, int N, int D, float inv_tau,
-                                                          float* __restrict__ logits, float* __restrict__ row_loss) {
+                                                          float* __restrict__ logits, float* __restrict__ row_loss,
+                                                          float* __restrict__ lse_out) {
+    // labels == nullptr: the positive of row i is column i (column term: rows are texts, columns proteins)
     __shared__ float red[4];
     const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* p = seg + (int64_t)i * D;
@@ -181,14 +183,19 @@ __global__ void __launch_bounds__(256) infonce_fwd_kernel(const float* __restric
     float se = 0.f;
     for (int j = threadIdx.x; j < N; j += 256) se += expf(lrow[j] - mx);
     se = block_sum<4>(se, red);
-    if (threadIdx.x == 0) row_loss[i] = (mx + logf(se)) - lrow[labels[i]];
+    if (threadIdx.x == 0) {
+        const float lse = mx + logf(se);
+        row_loss[i] = lse - lrow[labels ? labels[i] : i];
+        if (lse_out) lse_out[i] = lse;
+    }
 }
 
-__global__ void __launch_bounds__(256) infonce_reduce_kernel(const float* __restrict__ row_loss, int S, float weight,
-                                                             int accumulate, float* __restrict__ loss_out) {
+__global__ void __launch_bounds__(256) infonce_reduce_kernel(const float* __restrict__ row_loss, const int32_t* __restrict__ which,
+                                                             int first, int S, float weight, int accumulate,
+                                                             float* __restrict__ loss_out) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < S; i += 256) s += row_loss[i];
+    for (int i = threadIdx.x; i < S; i += 256) s += row_loss[which ? which[i] : first + i];
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) {
         const float v = weight * s / (float)S;
@@ -196,10 +203,14 @@ __global__ void __launch_bounds__(256) infonce_reduce_kernel(const float* __rest
     }
 }
 
-// d_seg[i, c] = weight / (S tau) * sum_j (softmax_ij - [j == y_i]) batch[j, c]
+// Row term (col_lse == nullptr):  d_seg[i, c] = weight / (S tau) * sum_j (softmax_ij - [j == y_i]) batch[j, c].
+// Column term (col_lse = log-sum-exp of every COLUMN j over all rows of the global batch):
+//   d_seg[i, c] (+)= weight / tau * sum_j (exp(l_ij - col_lse_j) - [j == y_i]) batch[j, c]
+// -- the derivative of sum_j (col_lse_j - l_jj) with respect to row i, which reaches row i through every column.
 __global__ void __launch_bounds__(256) infonce_bwd_kernel(const float* __restrict__ batch, const int32_t* __restrict__ labels,
-                                                          const float* __restrict__ logits, int S, int N, int D,
-                                                          float inv_tau, float weight, float* __restrict__ d_seg) {
+                                                          const float* __restrict__ logits, const float* __restrict__ col_lse,
+                                                          int S, int N, int D, float inv_tau, float weight, int accumulate,
+                                                          float* __restrict__ d_seg) {
     extern __shared__ float coef[];            // N floats
     __shared__ float red[4];
     const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -213,9 +224,12 @@ __global__ void __launch_bounds__(256) infonce_bwd_kernel(const float* __restric
     float se = 0.f;
     for (int j = threadIdx.x; j < N; j += 256) se += expf(lrow[j] - mx);
     se = block_sum<4>(se, red);
-    const float sc = weight * inv_tau / (float)S;
+    const float sc = col_lse ? weight * inv_tau : weight * inv_tau / (float)S;
     const int y = labels[i];
-    for (int j = threadIdx.x; j < N; j += 256) coef[j] = (expf(lrow[j] - mx) / se - (j == y ? 1.f : 0.f)) * sc;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float pj = col_lse ? expf(lrow[j] - col_lse[j]) : expf(lrow[j] - mx) / se;
+        coef[j] = (pj - (j == y ? 1.f : 0.f)) * sc;
+    }
     __syncthreads();
     for (int c = threadIdx.x * 4; c < D; c += 1024) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -225,6 +239,11 @@ __global__ void __launch_bounds__(256) infonce_bwd_kernel(const float* __restric
             const float cj = coef[j];
             acc[0] = fmaf(cj, bb[0], acc[0]); acc[1] = fmaf(cj, bb[1], acc[1]);
             acc[2] = fmaf(cj, bb[2], acc[2]); acc[3] = fmaf(cj, bb[3], acc[3]);
+        }
+        if (accumulate) {
+            float old[4];
+            load4(d_seg + (int64_t)i * D + c, old);
+            acc[0] += old[0]; acc[1] += old[1]; acc[2] += old[2]; acc[3] += old[3];
         }
         store4(d_seg + (int64_t)i * D + c, acc);
     }
@@ -270,9 +289,9 @@ extern "C" int p2t_infonce_forward(const float* seg, const float* batch, const i
     P2T_REQUIRE(seg && batch && labels && loss_out && logits && row_loss && S > 0 && N > 0 && D > 0 && D % 4 == 0 && temperature > 0.f,
                 "p2t_infonce_forward: bad arguments (logits [S,N] and row_loss [S] scratch are required, D %% 4 == 0)");
     hipStream_t s = (hipStream_t)stream;
-    infonce_fwd_kernel<<<S, 256, 0, s>>>(seg, batch, labels, N, D, 1.0f / temperature, logits, row_loss);
+    infonce_fwd_kernel<<<S, 256, 0, s>>>(seg, batch, labels, N, D, 1.0f / temperature, logits, row_loss, nullptr);
     P2T_LAUNCH_CHECK();
-    infonce_reduce_kernel<<<1, 256, 0, s>>>(row_loss, S, weight, accumulate, loss_out);
+    infonce_reduce_kernel<<<1, 256, 0, s>>>(row_loss, nullptr, 0, S, weight, accumulate, loss_out);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }
@@ -281,8 +300,33 @@ extern "C" int p2t_infonce_backward(const float* batch, const int32_t* labels, c
                                     float temperature, float weight, float* d_seg, p2t_stream stream) {
     P2T_REQUIRE(batch && labels && logits && d_seg && S > 0 && N > 0 && N <= 8192 && D > 0 && D % 4 == 0 && temperature > 0.f,
                 "p2t_infonce_backward: bad arguments (N <= 8192, D %% 4 == 0)");
-    infonce_bwd_kernel<<<S, 256, (size_t)N * sizeof(float), (hipStream_t)stream>>>(batch, labels, logits, S, N, D,
-                                                                                   1.0f / temperature, weight, d_seg);
+    infonce_bwd_kernel<<<S, 256, (size_t)N * sizeof(float), (hipStream_t)stream>>>(batch, labels, logits, nullptr, S, N, D,
+                                                                                   1.0f / temperature, weight, 0, d_seg);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_infonce_col_forward(const float* p_all, const float* t_all, int N, int D, float temperature, const int32_t* cols,
+                                       int first, int count, float weight, int accumulate, float* loss_out, float* col_lse,
+                                       float* scratch_logits, float* scratch_col_loss, p2t_stream stream) {
+    P2T_REQUIRE(p_all && t_all && loss_out && col_lse && scratch_logits && scratch_col_loss && N > 0 && D > 0 && D % 4 == 0 &&
+                    temperature > 0.f && count > 0 && count <= N && (cols || (first >= 0 && first + count <= N)),
+                "p2t_infonce_col_forward: bad arguments (scratch_logits [N,N], scratch_col_loss [N], D %% 4 == 0)");
+    hipStream_t s = (hipStream_t)stream;
+    // rows = texts, columns = proteins: the same kernel as the row term with the operands swapped (logits^T)
+    infonce_fwd_kernel<<<N, 256, 0, s>>>(t_all, p_all, nullptr, N, D, 1.0f / temperature, scratch_logits, scratch_col_loss, col_lse);
+    P2T_LAUNCH_CHECK();
+    infonce_reduce_kernel<<<1, 256, 0, s>>>(scratch_col_loss, cols, first, count, weight, accumulate, loss_out);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_infonce_col_backward(const float* t_all, const int32_t* labels, const float* logits, const float* col_lse, int S,
+                                        int N, int D, float temperature, float scale, int accumulate, float* d_seg, p2t_stream stream) {
+    P2T_REQUIRE(t_all && labels && logits && col_lse && d_seg && S > 0 && N > 0 && N <= 8192 && D > 0 && D % 4 == 0 && temperature > 0.f,
+                "p2t_infonce_col_backward: bad arguments (N <= 8192, D %% 4 == 0)");
+    infonce_bwd_kernel<<<S, 256, (size_t)N * sizeof(float), (hipStream_t)stream>>>(t_all, labels, logits, col_lse, S, N, D,
+                                                                                   1.0f / temperature, scale, accumulate, d_seg);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -120,6 +120,8 @@ SIGNATURES = {
     "p2t_l2norm_rows_backward": (i32, [vp, vp, vp, i64, i64, f32, vp]),
     "p2t_infonce_forward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]),
     "p2t_infonce_backward": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, vp]),
+    "p2t_infonce_col_forward": (i32, [vp, vp, i32, i32, f32, vp, i32, i32, f32, i32, vp, vp, vp, vp, vp]),
+    "p2t_infonce_col_backward": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp]),
     "p2t_clip_adamw_step": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                                   C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), i32, i32, f64, f64, f64, f64, f64, f64,
                                   vp, vp, vp]),

@@ -26,7 +26,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from . import _lib, ops
+from . import _lib, ops, sharding
 from ._lib import call
 from .ops import ptr, round_up, stream
 
@@ -67,19 +67,29 @@ class _NormalizeFn(torch.autograd.Function):
 
 
 class _InfoNCEFn(torch.autograd.Function):
+    """(1 - cw) * row term + cw * column term.  Row term: the reference's SegmentedBatchInfoNCELoss.  Column term (cw > 0):
+    mean over the segment's OWN columns of logsumexp_i(l_ij) - l_jj with i over `all1` (every first-side embedding of the
+    batch, detached); the backward gives each segment row its share of the column term of EVERY column, so that the
+    mean over segments, as teacher_forcing_forward_pass forms it, has the exact gradient of the whole-batch loss."""
+
     @staticmethod
-    def forward(ctx, seg, batch, labels, temperature):
-        loss, logits = ops.infonce_forward(seg, batch, labels, temperature)
-        ctx.save_for_backward(batch, labels, logits)
-        ctx.temperature = temperature
+    def forward(ctx, seg, batch, labels, temperature, all1, cw):
+        loss, logits = ops.infonce_forward(seg, batch, labels, temperature, 1.0 - cw)
+        col_lse = None
+        if cw > 0.0:
+            _, col_lse = ops.infonce_col_forward(all1, batch, temperature, cols=labels, weight=cw, loss_out=loss, accumulate=True)
+        ctx.save_for_backward(batch, labels, logits, col_lse) if col_lse is not None else ctx.save_for_backward(batch, labels, logits)
+        ctx.temperature, ctx.cw = temperature, cw
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        batch, labels, logits = ctx.saved_tensors
-        d = ops.infonce_backward(batch, labels, logits, ctx.temperature, 1.0)
+        batch, labels, logits = ctx.saved_tensors[:3]
+        d = ops.infonce_backward(batch, labels, logits, ctx.temperature, 1.0 - ctx.cw)
+        if ctx.cw > 0.0:
+            ops.infonce_col_backward(batch, labels, logits, ctx.saved_tensors[3], ctx.temperature, ctx.cw / logits.shape[0], d_seg=d)
         call("p2t_scale_by_device_scalar", ptr(d), d.numel(), ptr(g.float().reshape(1).contiguous()), stream())
-        return d, None, None, None
+        return d, None, None, None, None, None
 
 
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
@@ -108,13 +118,22 @@ def readout_embeddings(embeddings: torch.Tensor, attention_mask: Optional[torch.
 
 class SegmentedBatchInfoNCELoss(nn.Module):
     """Row-wise InfoNCE of a segment against the whole batch (reference :94-114):
-    logits = seg @ batch.T / temperature; loss = -mean_i log softmax(logits_i)[labels_i]."""
+    logits = seg @ batch.T / temperature; loss = -mean_i log softmax(logits_i)[labels_i].
 
-    def __init__(self, temperature: float = 0.05):
+    `column_weight` (default 0 = the reference's row-only loss) adds the column (text -> protein) term named by
+    BASELINE.json north_star: loss = (1 - cw) * row + cw * column, column = F.cross_entropy(logits^T, arange) -- the
+    reference's own BatchInfoNCELoss with swapped arguments (:72-91) -- restricted to the segment's own columns; it needs
+    `batch_output1`, the first-side embeddings of the WHOLE batch (values only).  Gradients reach `segment_output1` only:
+    the text side is frozen on this path (:186-187, :348-354)."""
+
+    def __init__(self, temperature: float = 0.05, column_weight: float = 0.0):
         super().__init__()
-        self.temperature = temperature
+        if not 0.0 <= column_weight <= 1.0:
+            raise ValueError("column_weight must lie in [0, 1]")
+        self.temperature, self.column_weight = temperature, float(column_weight)
 
-    def forward(self, segment_output1: torch.Tensor, batch_output2: torch.Tensor, labels: torch.Tensor):
+    def forward(self, segment_output1: torch.Tensor, batch_output2: torch.Tensor, labels: torch.Tensor,
+                batch_output1: Optional[torch.Tensor] = None):
         if segment_output1.dim() != 2 or batch_output2.dim() != 2 or segment_output1.shape[1] != batch_output2.shape[1]:
             raise ValueError("expected segment_output1 (segment_size, dim) and batch_output2 (bsz, dim)")
         if labels.numel() != segment_output1.shape[0]:
@@ -123,21 +142,29 @@ class SegmentedBatchInfoNCELoss(nn.Module):
             raise NotImplementedError("gradients flow to the first argument only (the text side is frozen on this path)")
         seg = segment_output1.float().contiguous()
         bat = batch_output2.detach().float().contiguous()
-        return _InfoNCEFn.apply(seg, bat, labels, float(self.temperature))
+        all1 = None
+        if self.column_weight > 0.0:
+            if batch_output1 is None or tuple(batch_output1.shape) != tuple(bat.shape):
+                raise ValueError("the column term needs batch_output1: the (bsz, dim) first-side embeddings of the whole batch")
+            all1 = batch_output1.detach().float().contiguous()
+        return _InfoNCEFn.apply(seg, bat, labels, float(self.temperature), all1, self.column_weight)
 
 
 class BatchInfoNCELoss(nn.Module):
-    """In-batch InfoNCE, positives on the diagonal (reference :72-91)."""
+    """In-batch InfoNCE, positives on the diagonal (reference :72-91).  `symmetric=True` (off by default, not in the
+    reference loop): the mean of the row and the column cross-entropy, 0.5 * (L(out1, out2) + L(out2, out1))."""
 
-    def __init__(self, temperature: float = 0.05):
+    def __init__(self, temperature: float = 0.05, symmetric: bool = False):
         super().__init__()
-        self.temperature = temperature
+        self.temperature, self.symmetric = temperature, bool(symmetric)
 
     def forward(self, batch_output1: torch.Tensor, batch_output2: torch.Tensor):
         if batch_output1.shape != batch_output2.shape:
             raise ValueError("BatchInfoNCELoss expects two (bsz, dim) tensors of the same shape")
         labels = torch.arange(batch_output1.shape[0], device=batch_output1.device)
-        return SegmentedBatchInfoNCELoss(self.temperature)(batch_output1, batch_output2, labels)
+        cw = 0.5 if self.symmetric else 0.0
+        return SegmentedBatchInfoNCELoss(self.temperature, cw)(batch_output1, batch_output2, labels,
+                                                               batch_output1 if self.symmetric else None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -164,25 +191,20 @@ def get_description_embeddings(model, description_input_ids: torch.Tensor, descr
     return readout_embeddings(hidden_states, description_attention_mask, readout_fn)
 
 
-def _gather_text(t_local: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:
-    """All-gather the (no-grad) normalised text embeddings: returns ([world*B_loc, D], this rank's row offset)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return t_local, 0
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    out = torch.empty((world * t_local.shape[0], t_local.shape[1]), dtype=t_local.dtype, device=t_local.device)
-    dist.all_gather_into_tensor(out, t_local.contiguous(), group=group)
-    return out, rank * t_local.shape[0]
+_gather_text = sharding.gather_rows       # all-gather of the (no-grad) normalised text embeddings, rank order
 
 
 def teacher_forcing_forward_pass(rank, model, data_batch: Dict[str, Any], contrastive_num_segments: int, *,
                                  output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
                                  global_negatives: bool = False, temperature: float = 0.05,
-                                 trim_padding: bool = False, trim_multiple: int = 128) -> torch.Tensor:
+                                 trim_padding: bool = False, trim_multiple: int = 128, column_weight: float = 0.0) -> torch.Tensor:
     """One forward of the contrastive step (reference :313-379); the returned loss carries the autograd
     graph through the adapter.  `global_negatives=True` scores against the all-gathered global batch
     (the reference uses per-rank negatives; with world size 1 the two coincide).
     `trim_padding=True`: each (equal) segment runs at the padded length of ITS longest protein, read from the host-side
-    `data_batch["protein_lengths"]` (data.sort_batch_by_length) -- same loss with the mask-aware readout."""
+    `data_batch["protein_lengths"]` (data.sort_batch_by_length) -- same loss with the mask-aware readout.
+    `column_weight` > 0 adds the column (text -> protein) term (SegmentedBatchInfoNCELoss): every segment is encoded first,
+    the protein embeddings are all-gathered like the text ones, then the segments are scored."""
     if trim_padding and ones_mask:
         raise ValueError("trim_padding needs the mask-aware readout (ones_mask=False)")
     base = model.module if hasattr(model, "module") else model
@@ -200,19 +222,32 @@ def teacher_forcing_forward_pass(rank, model, data_batch: Dict[str, Any], contra
     offset = 0
     if global_negatives:
         description_output, offset = _gather_text(description_output)
-    loss_fn = SegmentedBatchInfoNCELoss(temperature)
+    loss_fn = SegmentedBatchInfoNCELoss(temperature, column_weight)
     acc_loss = torch.zeros([], device=dev)
     lengths = data_batch.get("protein_lengths") if trim_padding else None
     if trim_padding and (lengths is None or len(lengths) != batch_size or (torch.is_tensor(lengths) and lengths.is_cuda)):
         raise ValueError("trim_padding=True needs data_batch['protein_lengths']: one host int per pair")
-    for s in range(contrastive_num_segments):
+    if column_weight > 0.0 and segment_size * contrastive_num_segments != batch_size:
+        raise ValueError("the column term needs every pair on both sides: batch size must be divisible by the segments")
+
+    def encode_segment(s):
         sl = slice(s * segment_size, (s + 1) * segment_size)
         Ts = pid.shape[1]
         if lengths is not None:
             Ts = min(Ts, round_up(max(1, max(int(v) for v in lengths[sl])), trim_multiple))
-        seg = l2_normalize(get_sequence_embeddings(base, pid[sl, :Ts], pmask[sl, :Ts], readout_fn, ones_mask))
-        labels = torch.arange(sl.start, sl.stop, device=dev) + offset
-        acc_loss = acc_loss + loss_fn(segment_output1=seg, batch_output2=description_output, labels=labels)
+        return l2_normalize(get_sequence_embeddings(base, pid[sl, :Ts], pmask[sl, :Ts], readout_fn, ones_mask))
+
+    segs, protein_all = None, None
+    if column_weight > 0.0:                  # the column log-sum-exps run over EVERY protein: encode all segments first
+        segs = [encode_segment(s) for s in range(contrastive_num_segments)]
+        protein_all = torch.cat([x.detach() for x in segs], 0)
+        if global_negatives:
+            protein_all, _ = sharding.gather_rows(protein_all)
+    for s in range(contrastive_num_segments):
+        seg = segs[s] if segs is not None else encode_segment(s)
+        labels = torch.arange(s * segment_size, (s + 1) * segment_size, device=dev) + offset
+        acc_loss = acc_loss + loss_fn(segment_output1=seg, batch_output2=description_output, labels=labels,
+                                      batch_output1=protein_all)
     return acc_loss / contrastive_num_segments
 
 
@@ -269,12 +304,18 @@ class ContrastiveTrainer:
                  num_segments: int = 1, output_llm_layer: int = 16, readout_fn: str = "mix", ones_mask: bool = False,
                  temperature: float = 0.05, train_mode: bool = True, global_negatives: bool = True, process_group=None,
                  overlap_streams: Optional[bool] = None, schedule=None, trim_padding: bool = False, trim_multiple: int = 128,
-                 trim_floor_tokens: int = 4096, gradient_accumulation_steps: int = 1):
+                 trim_floor_tokens: int = 4096, gradient_accumulation_steps: int = 1, column_weight: float = 0.0,
+                 schedule_step: str = "epoch"):
         if trim_padding and ones_mask:
             raise ValueError("trim_padding needs the mask-aware readout: with ones_mask=True (the fork's quirk, "
                              "train_contrast.py:269-275) the padded positions are part of the result")
         if trim_multiple <= 0 or trim_multiple % 64:
             raise ValueError("trim_multiple must be a positive multiple of 64")
+        if not 0.0 <= column_weight <= 1.0:
+            raise ValueError("column_weight must lie in [0, 1]")
+        if schedule_step not in ("epoch", "step"):
+            raise ValueError("schedule_step must be 'epoch' (the reference: scheduler.step() once per epoch) or 'step'")
+        self.column_weight, self.schedule_step = float(column_weight), schedule_step
         self.trim_padding, self.trim_multiple, self.trim_floor_tokens = trim_padding, trim_multiple, trim_floor_tokens
         self.model = model
         self.schedule = schedule                   # training_state.CosineWarmupSchedule or None (constant lr)
@@ -319,14 +360,17 @@ class ContrastiveTrainer:
         self.scratch = torch.empty((256 * 4,), dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros((1,), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((1,), dtype=torch.float32, device=dev)
-        self._buf = {}
+        self._bufs = {}
+        self._col_lse = None
 
     # ------------------------------------------------------------------------------------------
-    def _buffers(self, Bs: int, T: int):
-        """Adapter activations / gradients for M = Bs * T rows: ONE grow-only set sized for the largest M seen, handed
-        out as leading-row views, so ragged segment shapes (trim_padding) do not multiply the footprint."""
+    def _buffers(self, Bs: int, T: int, slot: int = 0):
+        """Adapter activations / gradients for M = Bs * T rows: ONE grow-only set (per slot) sized for the largest M seen,
+        handed out as leading-row views, so ragged segment shapes (trim_padding) do not multiply the footprint.  Slots > 0
+        exist only with the column term, where every segment's forward state lives until its backward."""
         M = Bs * T
-        cap = self._buf.get("cap", 0)
+        bufs = self._bufs.setdefault(slot, {})
+        cap = bufs.get("cap", 0)
         if M > cap:
             c, dev, dt = self.c, self.dev, self.tdt
             ld1, ld2 = round_up(c.intermediate_dim, 64), round_up(c.output_dim, 64)
@@ -339,8 +383,9 @@ class ContrastiveTrainer:
             full["ws"] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             full["saved"] = _lib.AdapterSavedC(z1=full["z1"].data_ptr(), h1=full["h1"].data_ptr(), z2=full["z2"].data_ptr(),
                                                g2=full["g2"].data_ptr(), inv_norm=full["inv"].data_ptr())
-            self._buf = {"cap": M, "full": full}
-        full = self._buf["full"]
+            bufs.clear()
+            bufs.update({"cap": M, "full": full})
+        full = bufs["full"]
         b = {k: (v[:M] if k in ("z1", "h1", "z2", "g2", "y", "inv", "dY") else v) for k, v in full.items()}
         return b
 
@@ -384,75 +429,106 @@ class ContrastiveTrainer:
         all-reduce-averaged over ranks).  No host synchronisation.  backward=False stops after the loss.
         accumulate: add the gradients to self.g instead of overwriting (the loss is always this batch's own);
         grad_scale: factor on the gradients only (1 / gradient_accumulation_steps: `loss / GA` before `backward()`,
-        train_contrast.py:428-448); reduce=False leaves the cross-rank average to a later call (sums commute with it)."""
+        train_contrast.py:428-448); reduce=False leaves the cross-rank average to a later call (sums commute with it).
+        The rank logic (gather, label offsets, gradient average) is sharding.sharded_forward_backward; the closures below
+        are the kernels between its collectives."""
         m, c = self.model, self.c
         pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
         tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
         B, T = pid.shape
         segs = self._segments(batch, B, T)
+        cw = self.column_weight
+        if cw > 0.0 and (segs[0][0] != 0 or segs[-1][1] != B or tid.shape[0] != B):
+            raise ValueError("the column term needs every pair on both sides: batch size must be divisible by num_segments")
+        # packed weight copies are built on the CALLER's stream, before any side stream reads them
+        m.esm_encoder.ensure_engine()
+        m.llama_decoder.model.ensure_engine(self.layer)
         # The text tower and the ESM2 encodes of the segments are independent until the loss: they are enqueued on
         # separate HIP streams so the tail of one kernel's grid (M = 2048 text GEMMs, 2.5-"round" encoder GEMMs)
         # is filled by another stream's blocks instead of idling CUs.  Everything joins on the caller's stream.
         main = torch.cuda.current_stream()
-        encs = []
+        encs, pre = {}, {}
         if self.overlap_streams:
             start = main.record_event()
             with torch.cuda.stream(self._stream(0)):
                 torch.cuda.current_stream().wait_event(start)
-                t_local = self.text_embeddings(tid, tmask, batch)
-                t_local.record_stream(main)
-                ev_text = torch.cuda.current_stream().record_event()
+                pre["text"] = self.text_embeddings(tid, tmask, batch)
+                pre["text"].record_stream(main)
+                pre["ev"] = torch.cuda.current_stream().record_event()
             for s, (r0, r1, Ts, _) in enumerate(segs):
                 with torch.cuda.stream(self._stream(1 + s % 2)):
                     torch.cuda.current_stream().wait_event(start)
                     enc = m.esm_encoder.encode(pid[r0:r1, :Ts], pmask[r0:r1, :Ts])
                     enc.record_stream(main)
-                    encs.append((enc, torch.cuda.current_stream().record_event()))
-            main.wait_event(ev_text)
-        else:
-            t_local = self.text_embeddings(tid, tmask, batch)
-        if self.global_negatives:
-            t_all, offset = _gather_text(t_local, self.group)
-        else:
-            t_all, offset = t_local, 0
+                    encs[s] = (enc, torch.cuda.current_stream().record_event())
+
+        def text_fn():
+            if pre:
+                main.wait_event(pre["ev"])
+                return pre["text"]
+            return self.text_embeddings(tid, tmask, batch)
+
         p_drop = float(m.adapter.dropout.p) if self.train_mode else 0.0
         wts = _lib.AdapterWeightsC(fc1_w=self.w1.data_ptr(), fc1_b=self.p[1].data_ptr(), fc2_w=self.w2.data_ptr(),
                                    fc2_b=self.p[3].data_ptr())
         mode = self.readout_fn
-        for s, (r0, r1, T, weight) in enumerate(segs):       # T: this segment's own padded length
+        states = {}
+
+        def seg_forward(s, r0, r1, Ts, slot):
+            """encoder -> adapter forward -> readout -> normalise for rows r0..r1 at padded length Ts; activations in
+            buffer set `slot` (one shared set when segments are finished one after the other)."""
             sl, Bs = slice(r0, r1), r1 - r0
-            ids_s, mask_s = pid[sl, :T], pmask[sl, :T]
-            if encs:
+            ids_s, mask_s = pid[sl, :Ts], pmask[sl, :Ts]
+            if s in encs:
                 enc, ev = encs[s]
                 main.wait_event(ev)
             else:
-                enc = m.esm_encoder.encode(ids_s, mask_s)                              # [Bs, T, Hp]
-            Hp, M = enc.shape[2], Bs * T
-            b = self._buffers(Bs, T)
+                enc = m.esm_encoder.encode(ids_s, mask_s)                              # [Bs, Ts, Hp]
+            Hp, M = enc.shape[2], Bs * Ts
+            b = self._buffers(Bs, Ts, slot)
             seed = m.adapter._next_seed() if p_drop > 0 else 0
             cfg = _lib.AdapterConfigC(input_dim=c.input_dim, intermediate_dim=c.intermediate_dim, output_dim=c.output_dim,
                                       dropout_p=p_drop, dropout_seed=seed, dtype=ops.dt_of(self.tdt))
             call("p2t_adapter_forward", C.byref(cfg), C.byref(wts), ptr(enc), Hp, M, ptr(b["y"]), C.byref(b["saved"]), stream())
-            y3 = b["y"].view(Bs, T, -1)
+            y3 = b["y"].view(Bs, Ts, -1)
             rmask = None if self.ones_mask else mask_s
             pooled_mix = ops.readout(y3, rmask, "mix", D=c.output_dim) if mode in ("std", "mix") else None
             pooled = pooled_mix if mode == "mix" else ops.readout(y3, rmask, mode, D=c.output_dim)
-            p = ops.l2norm_rows(pooled)
-            labels = torch.arange(sl.start + offset, sl.stop + offset, device=self.dev, dtype=torch.int32)
-            _, logits = ops.infonce_forward(p, t_all, labels, self.temperature, weight, self.loss, accumulate=s > 0)
+            return dict(enc=enc, Hp=Hp, M=M, b=b, cfg=cfg, y3=y3, rmask=rmask, pooled_mix=pooled_mix, pooled=pooled,
+                        p=ops.l2norm_rows(pooled), Bs=Bs, Ts=Ts)
+
+        def protein_fn():
+            """Column term only: the forward of EVERY segment first (activations kept per segment for the backward)."""
+            for s, (r0, r1, Ts, _) in enumerate(segs):
+                states[s] = seg_forward(s, r0, r1, Ts, slot=s)
+            return torch.cat([states[s]["p"] for s in range(len(segs))], 0)
+
+        def column_fn(p_all, t_all, offset):
+            _, self._col_lse = ops.infonce_col_forward(p_all, t_all, self.temperature, first=offset, count=B, weight=cw,
+                                                       loss_out=self.loss, accumulate=False)
+
+        def segment_fn(s, r0, r1, Ts, weight, t_all, labels, offset):
+            st = states.pop(s) if s in states else seg_forward(s, r0, r1, Ts, slot=0)
+            _, logits = ops.infonce_forward(st["p"], t_all, labels, self.temperature, weight * (1.0 - cw), self.loss,
+                                            accumulate=s > 0 or cw > 0.0)
             if not backward:
-                continue
-            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, weight * grad_scale)
-            dpooled = ops.l2norm_rows_backward(pooled, dp)
+                return
+            dp = ops.infonce_backward(t_all, labels, logits, self.temperature, weight * (1.0 - cw) * grad_scale)
+            if cw > 0.0:      # every column's log-sum-exp depends on this row: scale cw * weight / n_s = cw / B_loc per row
+                ops.infonce_col_backward(t_all, labels, logits, self._col_lse, self.temperature,
+                                         cw * weight * grad_scale / st["Bs"], d_seg=dp)
+            dpooled = ops.l2norm_rows_backward(st["pooled"], dp)
+            b, y3, rmask = st["b"], st["y3"], st["rmask"]
             call("p2t_readout_backward", ptr(y3), ops.dt_of(y3), y3.stride(1), ptr(rmask.to(torch.int64).contiguous()) if rmask is not None else None,
-                 Bs, T, c.output_dim, _lib.READOUT[mode], ptr(pooled_mix), ptr(dpooled), ptr(b["dY"]), stream())
-            call("p2t_adapter_backward", C.byref(cfg), C.byref(wts), ptr(enc), Hp, M, C.byref(b["saved"]), ptr(b["dY"]),
+                 st["Bs"], st["Ts"], c.output_dim, _lib.READOUT[mode], ptr(st["pooled_mix"]), ptr(dpooled), ptr(b["dY"]), stream())
+            call("p2t_adapter_backward", C.byref(st["cfg"]), C.byref(wts), ptr(st["enc"]), st["Hp"], st["M"], C.byref(b["saved"]), ptr(b["dY"]),
                  ptr(self.g[0]), ptr(self.g[1]), ptr(self.g[2]), ptr(self.g[3]), int(s > 0 or accumulate), ptr(b["ws"]),
                  b["ws"].numel(), stream())
-        if backward and reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG if self.flat_g.is_cuda else dist.ReduceOp.SUM, group=self.group)
-            if not self.flat_g.is_cuda:
-                self.flat_g /= dist.get_world_size(self.group)
+
+        sharding.sharded_forward_backward(text_fn=text_fn, segment_fn=segment_fn, segments=segs,
+                                          global_negatives=self.global_negatives, flat_g=self.flat_g, backward=backward,
+                                          reduce=reduce, group=self.group, protein_fn=protein_fn if cw > 0.0 else None,
+                                          column_fn=column_fn if cw > 0.0 else None)
         return self.loss
 
     def _segments(self, batch, B: int, T: int):
@@ -483,25 +559,32 @@ class ContrastiveTrainer:
         return [(a, b, Ts, (b - a) / B) for a, b, Ts in plan]
 
     def optimizer_step(self):
-        """clip_grad_norm_ -> AdamW.step -> scheduler.step (train_contrast.py:453-465)."""
+        """clip_grad_norm_ -> AdamW.step -> zero_grad (train_contrast.py:453-465) at the schedule's current learning rate.
+        The reference advances its LambdaLR ONCE PER EPOCH (`scheduler.step()` after `train_epoch`, :654-662), although
+        the schedule is sized in optimizer steps (:626-637): call `end_epoch()` where the reference does.
+        `schedule_step="step"` advances it here instead, after every optimizer step (the conventional reading)."""
         self.step_count += 1
         hp = dict(self.hp)
         if self.schedule is not None:
             hp["lr"] = self.schedule.lr()
         ops.clip_adamw_step(self.p, self.g, self.m, self.v, self.step_count, shadows=[self.w1, None, self.w2, None],
                             scratch=self.scratch, grad_norm_out=self.grad_norm, **hp)
-        if self.schedule is not None:
+        if self.schedule is not None and self.schedule_step == "step":
             self.schedule.step()
         return self.grad_norm
 
+    def end_epoch(self):
+        """`scheduler.step()` of the reference's epoch loop (train_contrast.py:662); a no-op with schedule_step="step"."""
+        if self.schedule is not None and self.schedule_step == "epoch":
+            self.schedule.step()
+
     def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """One micro-batch of `train_epoch` (train_contrast.py:417-465): gradients of loss / GA are accumulated, and every
-        `gradient_accumulation_steps` calls clip + AdamW + scheduler run.  Returns this batch's (unscaled) loss."""
-        ga = self.gradient_accumulation_steps
-        last = self._micro == ga - 1
-        loss = self.forward_backward(batch, accumulate=self._micro > 0, grad_scale=1.0 / ga, reduce=last)
+        `gradient_accumulation_steps` calls clip + AdamW run.  Returns this batch's (unscaled) loss."""
+        accumulate, grad_scale, reduce, do_step = sharding.micro_step_plan(self._micro, self.gradient_accumulation_steps)
+        loss = self.forward_backward(batch, accumulate=accumulate, grad_scale=grad_scale, reduce=reduce)
         self._micro += 1
-        if last:
+        if do_step:
             self.optimizer_step()
             self._micro = 0
         return loss

@@ -184,6 +184,10 @@ class EsmEncoder(nn.Module):
         self._engine = dict(cfg=cfg, w=w, layers=layers, keep=keep, Hp=Hp)
         return self._engine
 
+    def ensure_engine(self):
+        """Build the packed weight copies now, on the current stream (callers that fan out to side streams do this first)."""
+        return self._engine or self._build_engine()
+
     def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
         """-> padded last_hidden_state [B, T, Hp] (columns >= hidden are zero; the adapter reads it as is)."""
         if input_ids is None or input_ids.dim() != 2:
@@ -434,6 +438,11 @@ class LlamaTextModel(nn.Module):
             medium = ~(wavelen < high_wl) * ~(wavelen > low_wl)
             inv = torch.where(medium, smoothed, inv_l)
         return inv.float().contiguous()
+
+    def ensure_engine(self, k: int):
+        """Packed weights of the first k layers, built now on the current stream if missing."""
+        e = self._engine
+        return e if (e is not None and e["n"] >= k) else self._build_engine(k)
 
     def hidden_state(self, input_ids, attention_mask, k: int) -> torch.Tensor:
         """hidden_states[k] as f32 [B, T, hidden] (k = n_layers -> post final RMSNorm)."""

@@ -270,6 +270,40 @@ def infonce_backward(batch, labels, logits, temperature=0.05, weight=1.0):
     return d_seg
 
 
+def infonce_col_forward(p_all, t_all, temperature=0.05, first=0, count=None, weight=1.0, loss_out=None, accumulate=False, cols=None):
+    """Column (text -> protein) term on the global [N, D] embeddings: returns (loss[1], col_lse [N]);
+    loss (+)= weight * mean over the columns j in `cols` (device int tensor) or first <= j < first + count of
+    (logsumexp_i l_ij - l_jj)."""
+    _chk(p_all.dtype == torch.float32 and t_all.dtype == torch.float32 and p_all.dim() == 2 and p_all.shape == t_all.shape,
+         "infonce_col: f32 [N, D] protein and text embeddings of the same (global) batch")
+    N, D = p_all.shape
+    if cols is not None:
+        cols = cols.to(torch.int32).contiguous()
+        count = cols.numel()
+    count = N - first if count is None else count
+    if loss_out is None:
+        loss_out = torch.zeros((1,), dtype=torch.float32, device=p_all.device)
+        accumulate = False
+    col_lse = torch.empty((N,), dtype=torch.float32, device=p_all.device)
+    scratch = torch.empty((N * N + N,), dtype=torch.float32, device=p_all.device)
+    call("p2t_infonce_col_forward", ptr(p_all.contiguous()), ptr(t_all.contiguous()), N, D, float(temperature), ptr(cols), int(first), int(count),
+         float(weight), int(accumulate), ptr(loss_out), ptr(col_lse), ptr(scratch), ptr(scratch[N * N:]), stream())
+    return loss_out, col_lse
+
+
+def infonce_col_backward(t_all, labels, logits, col_lse, temperature=0.05, scale=1.0, d_seg=None):
+    """d_seg (+)= scale / tau * sum_j (exp(l_ij - col_lse_j) - [j == label_i]) t_j; adds to `d_seg` when given."""
+    S, N = logits.shape
+    D = t_all.shape[1]
+    labels = labels.to(torch.int32).contiguous()
+    acc = d_seg is not None
+    if d_seg is None:
+        d_seg = torch.empty((S, D), dtype=torch.float32, device=t_all.device)
+    call("p2t_infonce_col_backward", ptr(t_all.contiguous()), ptr(labels), ptr(logits), ptr(col_lse), S, N, D, float(temperature),
+         float(scale), int(acc), ptr(d_seg), stream())
+    return d_seg
+
+
 def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step: int, *, lr=2e-4, betas=(0.9, 0.999), eps=1e-6,
                     weight_decay=0.01, max_norm=math.inf, shadows=None, scratch=None, grad_norm_out=None):
     """clip_grad_norm_ + AdamW.step on f32 tensors (train_contrast.py:453-465).  shadows[i]: optional 2-D

@@ -241,6 +241,16 @@ def run_ops(ref):
     out["loss_batch_t01"] = tc.BatchInfoNCELoss(temperature=0.1)(p, t).numpy()
     labels = torch.tensor([3, 4, 5])
     out["loss_seg"] = tc.SegmentedBatchInfoNCELoss()(p[3:6], t, labels).numpy()
+    # column (text -> protein) term: the reference's own loss module with its arguments swapped; gradients to the protein
+    # side by torch autograd through the reference's forward (the text side is frozen on this path)
+    out["loss_batch_swapped"] = tc.BatchInfoNCELoss()(t, p).numpy()
+    p_req = p.clone().requires_grad_(True)
+    sym = 0.5 * (tc.BatchInfoNCELoss()(p_req, t) + tc.BatchInfoNCELoss()(t, p_req))
+    sym.backward()
+    out["loss_symmetric"], out["grad_symmetric_p"] = sym.detach().numpy(), p_req.grad.numpy().copy()
+    p_req.grad = None
+    tc.BatchInfoNCELoss()(t, p_req).backward()
+    out["grad_swapped_p"] = p_req.grad.numpy().copy()
     path = os.path.join(HERE, "ops.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}")
@@ -297,10 +307,13 @@ def run_collate(ref):
 
 
 def run_train_state(ref):
-    """Four optimizer steps of the reference's training recipe on the tiny model (train_contrast.py:417-465, 621-637):
+    """Three epochs of two optimizer steps of the reference's training recipe on the tiny model, IN THE REFERENCE'S CALL
+    ORDER (train_contrast.py:417-465 inside an epoch; `scheduler.step()` once per epoch after it, :654-662):
     AdamW over model.parameters() + HF cosine schedule with warm-up, loss through the reference's readout / InfoNCE,
-    dropout 0 for determinism.  Stores the per-step loss and lr, the final adapter tensors, the parameter order and the
-    optimizer / scheduler state dicts in the format train_contrast.py:692-698 saves."""
+    dropout 0 for determinism.  With a warm-up of 2 the learning rate is 0 throughout epoch 1 (LambdaLR factor(0)), half
+    in epoch 2, full in epoch 3 -- the reference's behaviour, reproduced as is.  Stores the per-step loss and lr, the
+    final adapter tensors, the parameter order and the optimizer / scheduler state dicts in the format
+    train_contrast.py:692-698 saves (`last_epoch` = epochs completed)."""
     import json
     from transformers import get_cosine_schedule_with_warmup
     tc = ref.tc
@@ -319,7 +332,8 @@ def run_train_state(ref):
     sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=warmup, num_training_steps=total_steps)
     shim = types.SimpleNamespace(llm_decoder=model.llama_decoder)
     out = {"losses": [], "lrs": []}
-    for step in range(4):
+    steps_per_epoch = 2
+    for step in range(6):
         pid, pmask = synth.protein_batch(100 + step, B, T_p, [24, 15, 7, 3])
         tid, tmask = synth.text_batch(100 + step, B, T_t, 500, [12, 9, 5, 2], 510, 509)
         pid_t, pmask_t, tid_t, tmask_t = (torch.from_numpy(a) for a in (pid, pmask, tid, tmask))
@@ -332,14 +346,16 @@ def run_train_state(ref):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float("inf"))
         opt.step()
-        sched.step()
         opt.zero_grad(set_to_none=True)
         out["losses"].append(float(loss))
+        if (step + 1) % steps_per_epoch == 0:
+            sched.step()                       # once per epoch, after train_epoch (train_contrast.py:662)
     final = {n: prm.detach().clone() for n, prm in model.adapter.named_parameters()}
     torch.save({"optimizer_state_dict": opt.state_dict(), "scheduler_state_dict": sched.state_dict()},
                os.path.join(HERE, "train_state_optimizer_scheduler.pt"))
     torch.save(final, os.path.join(HERE, "train_state_model.pt"))
     meta = dict(param_names=names, losses=out["losses"], lrs=out["lrs"], lr=1e-3, total_steps=total_steps, warmup=warmup,
+                steps_per_epoch=steps_per_epoch,
                 B=B, T_p=T_p, T_t=T_t, layer=layer, esm=specs.spec_dict(esm), llama=specs.spec_dict(llama),
                 adapter=specs.spec_dict(ad))
     with open(os.path.join(HERE, "train_state.json"), "w") as f:

@@ -95,3 +95,41 @@ def test_edge_shapes_bf16_mfma_path(golden, shape, case):
     assert finite or bool((var == 0).any()), "non-finite gradients without a zero-variance column"
     if not (var == 0).any():
         assert finite
+
+
+@pytest.mark.parametrize("nseg", [1, 2])
+def test_column_term_trainer_vs_oracle(golden, nseg):
+    """ContrastiveTrainer(column_weight=0.5) and teacher_forcing_forward_pass(column_weight=0.5): loss and adapter
+    gradients against the oracle's symmetric step (the reference's loss module with swapped arguments for the column half)."""
+    import p2t_hip as P
+    meta = golden("tiny_d64")["meta"]
+    esm, llama, ad, pid, pmask, tid, tmask = case_setup(meta)
+    pid, pmask, tid, tmask = pid[:4], pmask[:4], tid[:4], tmask[:4]
+    k = meta["layers"][-1]
+    W = model_weights(esm, llama, ad, meta["seed_w"])
+    ref = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=k, with_grads=True, column_weight=0.5, num_segments=nseg)
+    row_only = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=k, num_segments=nseg)
+    assert abs(float(ref["loss"]) - float(row_only["loss"])) > 1e-3          # the column half changes the value
+    model = build_model(esm, llama, ad, torch.float32, meta["seed_w"])
+    batch = dict(protein_input_ids=to_dev(pid), protein_attention_mask=to_dev(pmask), description_input_ids=to_dev(tid),
+                 description_attention_mask=to_dev(tmask))
+    tr = P.ContrastiveTrainer(model, output_llm_layer=k, train_mode=False, num_segments=nseg, column_weight=0.5)
+    loss = float(to_np(tr.forward_backward(batch))[0])
+    assert abs(loss - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
+    for g, name in zip(tr.g, NAMES):
+        assert rel(to_np(g), ref["grads"][name]) < 5e-4, name
+    assert float(to_np(tr.evaluate(batch))[0]) == pytest.approx(loss, rel=1e-6)
+    # autograd surface
+    model.esm_encoder.requires_grad_(False); model.llama_decoder.requires_grad_(False)
+    model.adapter.requires_grad_(True)
+    model.train(); model.adapter.dropout.p = 0.0
+    l2 = P.teacher_forcing_forward_pass(0, model, batch, nseg, output_llm_layer=k, column_weight=0.5)
+    l2.backward()
+    assert abs(float(l2) - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
+    prm = dict(model.adapter.named_parameters())
+    for name in NAMES:
+        assert rel(to_np(prm[name[len("adapter."):]].grad), ref["grads"][name]) < 5e-4, name
+    with pytest.raises(ValueError):
+        P.ContrastiveTrainer(model, column_weight=1.5)
+    with pytest.raises(ValueError):
+        P.ContrastiveTrainer(model, num_segments=3, column_weight=0.5).forward_backward(batch)      # 4 pairs, 3 segments

@@ -333,6 +333,43 @@ def test_l2norm_and_infonce(ops):
     assert abs(float(to_np(acc)[0]) - float(two)) < 3e-6
 
 
+def test_infonce_column_term_vs_reference_swapped_arguments(ops, golden):
+    """Column (text -> protein) term: kernels and the loss modules against the reference's BatchInfoNCELoss applied with
+    swapped arguments and torch autograd through it (tests/golden/ops.npz, make_golden.py run_ops)."""
+    import p2t_hip as P
+    g = golden("ops")
+    p, t = g["p"], g["t"]
+    n = p.shape[0]
+    pd, td = to_dev(p), to_dev(t)
+    loss, col_lse = ops.infonce_col_forward(pd, td)
+    assert abs(float(to_np(loss)[0]) - float(g["loss_batch_swapped"])) < 2e-6 * max(1.0, abs(float(g["loss_batch_swapped"])))
+    lg = (p @ t.T / np.float32(0.05)).astype(np.float64)
+    assert rel(to_np(col_lse), np.log(np.exp(lg).sum(0))) < 1e-6
+    _, logits = ops.infonce_forward(pd, td, to_dev(np.arange(n)))
+    d = ops.infonce_col_backward(td, to_dev(np.arange(n)), logits, col_lse, scale=1.0 / n)
+    assert rel(to_np(d), g["grad_swapped_p"]) < 3e-6
+    # a sub-range / explicit column list of the mean, accumulated with a weight
+    acc = torch.full((1,), 2.0, device=dev())
+    ops.infonce_col_forward(pd, td, cols=to_dev(np.array([4, 1])), weight=0.5, loss_out=acc, accumulate=True)
+    assert abs(float(to_np(acc)[0]) - (2.0 + 0.5 * float(O.infonce_columns(p, t, [1, 4])))) < 3e-6
+    # module surface: symmetric BatchInfoNCELoss and its gradient to the first argument
+    pr = to_dev(p).requires_grad_(True)
+    sym = P.BatchInfoNCELoss(symmetric=True)(pr, td)
+    sym.backward()
+    assert abs(float(sym) - float(g["loss_symmetric"])) < 3e-6 * max(1.0, abs(float(g["loss_symmetric"])))
+    assert rel(to_np(pr.grad), g["grad_symmetric_p"]) < 3e-6
+    # segmented form with the column term: the mean over segments has the whole-batch value and gradient
+    pr2 = to_dev(p).requires_grad_(True)
+    lf = P.SegmentedBatchInfoNCELoss(column_weight=0.5)
+    tot = sum(lf(pr2[a:b], td, torch.arange(a, b, device=dev()), batch_output1=pr2) for a, b in ((0, 2), (2, 4), (4, 6))) / 3
+    tot.backward()
+    assert abs(float(tot) - float(g["loss_symmetric"])) < 3e-6 * max(1.0, abs(float(g["loss_symmetric"])))
+    assert rel(to_np(pr2.grad), g["grad_symmetric_p"]) < 3e-6
+    with pytest.raises(ValueError):
+        lf(pr2[:2], td, torch.arange(2, device=dev()))                      # column term without the whole first side
+    assert float(P.BatchInfoNCELoss()(pr, td)) == pytest.approx(float(g["loss_batch"]), rel=3e-6)     # default: row-only, as upstream
+
+
 @pytest.mark.parametrize("max_norm", [math.inf, 0.05])
 def test_clip_adamw(ops, max_norm):
     names = ["w1", "b1", "w2", "b2"]

@@ -17,6 +17,15 @@ def test_ops_readout_and_losses(golden):
     assert abs(O.infonce_batch(g["p"], g["t"]) - g["loss_batch"]) < 1e-5
     assert abs(O.infonce_batch(g["p"], g["t"], 0.1) - g["loss_batch_t01"]) < 1e-5
     assert abs(O.infonce_segmented(g["p"][3:6], g["t"], np.array([3, 4, 5])) - g["loss_seg"]) < 1e-5
+    # column (text -> protein) term == the reference's BatchInfoNCELoss with swapped arguments, values and autograd gradients
+    loss_c, gcol = O.infonce_columns(g["p"], g["t"], None, return_grad=True)
+    n = g["p"].shape[0]
+    assert abs(loss_c - g["loss_batch_swapped"]) < 1e-5
+    assert rel_err(gcol / n, g["grad_swapped_p"]) < 1e-5
+    _, grow, _ = O.infonce_segmented(g["p"], g["t"], np.arange(n), return_grad=True)
+    assert abs(0.5 * (O.infonce_batch(g["p"], g["t"]) + loss_c) - g["loss_symmetric"]) < 1e-5
+    assert rel_err(0.5 * grow + 0.5 * gcol / n, g["grad_symmetric_p"]) < 1e-5
+    assert abs(O.infonce_columns(g["p"], g["t"], [1, 4]) - np.mean([O.infonce_columns(g["p"], g["t"], [j]) for j in (1, 4)])) < 1e-6
 
 
 @pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])

@@ -125,13 +125,18 @@ def test_reference_checkpoint_files_have_the_documented_layout():
     want = [names.index(n) for n in ts.ADAPTER_PARAM_NAMES]
     assert sorted(sd["optimizer_state_dict"]["state"]) == want          # only the four trained tensors carry state
     assert sd["optimizer_state_dict"]["param_groups"][0]["params"] == list(range(len(names)))
-    assert sd["scheduler_state_dict"]["last_epoch"] == 4
+    # the reference advances its LambdaLR once per EPOCH (train_contrast.py:662): last_epoch counts epochs, the Adam
+    # step counts optimizer steps
+    n_steps, spe = len(meta["lrs"]), meta["steps_per_epoch"]
+    assert sd["scheduler_state_dict"]["last_epoch"] == n_steps // spe == 3
+    assert all(float(st["step"]) == n_steps for st in sd["optimizer_state_dict"]["state"].values())
     sched = ts.CosineWarmupSchedule(meta["lr"], meta["warmup"], meta["total_steps"])
     lrs = []
-    for _ in range(4):
+    for i in range(n_steps):
         lrs.append(sched.lr())
-        sched.step()
-    assert lrs == pytest.approx(meta["lrs"], rel=1e-12, abs=1e-18)
+        if (i + 1) % spe == 0:
+            sched.step()
+    assert lrs == pytest.approx(meta["lrs"], rel=1e-12, abs=1e-18) and lrs[0] == 0.0      # lr 0 through epoch 1, as upstream
     assert sched.lr() == pytest.approx(sd["scheduler_state_dict"]["_last_lr"][0], rel=1e-12)
     model_sd = torch.load(os.path.join(HERE, "golden", "train_state_model.pt"), weights_only=True)
     assert sorted(model_sd) == sorted(f"{m}.{p}" for m in ("fc1", "fc2", "ln1", "ln2") for p in ("weight", "bias"))
