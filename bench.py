@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="text tower and encoder segments on separate HIP streams (+1-3 %% throughput; per-kernel event times "
                          "then include co-running kernels, so the roofline block is only meaningful without it)")
-    ap.add_argument("--cpu-sample", type=int, default=1, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=1, help="pairs of the benchmarked config in the CPU-baseline sample")
+    ap.add_argument("--cpu-cfg2", action="store_true", help="also time config 2 on the CPU (1 warm-up + 1 repetition, ~1.5 min)")
     ap.add_argument("--no-batch64-check", action="store_true",
                     help="skip the extra (untimed-for-`value`) measurement at the north-star batch 64 x 1024")
     return ap.parse_args()
@@ -91,43 +92,98 @@ class _Rows:
         return out
 
 
-def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs):
-    """Oracle forward + loss on `n_pairs` pairs of the same workload, host cores only."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs, with_cfg2=False):
+    """The oracle (a numpy port of the reference algorithm, fp32) timed on the host cores, BASELINE.md section 3 protocol:
+    forward + InfoNCE only; config 1 (the reference's own CPU-runnable case) with 1 warm-up + 3 timed repetitions, mean
+    and min; the benchmarked config on `n_pairs` pair(s), scaled per pair ("extrapolated": the CPU time is linear in
+    pairs); config 2 the same way on request (--cpu-cfg2, ~1.5 min).  `value` is the figure for the benchmarked workload."""
     import numpy as np
     from oracle import p2t_oracle as O
-    from p2t_hip import synth
+    from oracle.weights import model_weights
+    from p2t_hip import specs, synth
     from threadpoolctl import threadpool_limits
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))          # the GPU box gives one GPU a 16-core share
-    pid, pmask = synth.protein_batch(1234, n_pairs, Tp)
-    tid, tmask = synth.text_batch(1234, n_pairs, Tt)
-    W = GpuWeights(model)
+    extra = {"cpu_model": _cpu_model()}
+
+    def timed_config(name, reps):
+        e_name, l_name, _, B, tp, tt = specs.CONFIGS[name]
+        e, l = specs.esm_spec(e_name), specs.llama_spec(l_name)
+        Wc = model_weights(e, l, specs.adapter_spec(e, l), 0, cache=True)
+        pid, pmask = synth.protein_batch(1234, B, tp)
+        tid, tmask = synth.text_batch(1234, B, tt)
+        times = []
+        for r in range(reps + 1):                               # repetition 0 is the warm-up (also materialises the weights)
+            t0 = time.perf_counter()
+            out = O.contrastive_step(e, l, Wc, pid, pmask, tid, tmask, layer=min(16, l.num_hidden_layers), num_segments=1)
+            if r:
+                times.append(time.perf_counter() - t0)
+        assert np.isfinite(out["loss"])
+        return {"samples_per_s_mean": round(B / float(np.mean(times)), 3), "samples_per_s_best": round(B / min(times), 3),
+                "s_per_step_mean": round(float(np.mean(times)), 3), "reps": reps, "batch": B, "T_p": tp, "T_t": tt}
+
     with threadpool_limits(limits=cores):
+        extra["cfg1"] = timed_config("cfg1", 3)
+        if with_cfg2:
+            extra["cfg2"] = timed_config("cfg2", 1)
+        pid, pmask = synth.protein_batch(1234, n_pairs, Tp)
+        tid, tmask = synth.text_batch(1234, n_pairs, Tt)
+        W = GpuWeights(model)
         t0 = time.perf_counter()
         out = O.contrastive_step(esm, llama, W, pid, pmask, tid, tmask, layer=min(16, llama.num_hidden_layers), num_segments=1)
         dt = time.perf_counter() - t0
     assert np.isfinite(out["loss"])
     work = dt - W.fetch_s
     return {"value": round(n_pairs / work, 5), "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_pairs} pair(s) of {cfg_name} (T_p={Tp}, T_t={Tt}): fp32 numpy/OpenBLAS oracle, forward + InfoNCE, "
-                      f"{cores} BLAS threads, {work:.1f} s of CPU work (+{W.fetch_s:.1f} s downloading the GPU model's weights, excluded)"}
+            "sample": f"{n_pairs} pair(s) of {cfg_name} (T_p={Tp}, T_t={Tt}), extrapolated per pair: fp32 numpy/OpenBLAS oracle, forward + InfoNCE, "
+                      f"{cores} BLAS threads, one un-warmed repetition, {work:.1f} s of CPU work (+{W.fetch_s:.1f} s downloading the GPU model's "
+                      f"weights, excluded); cfg1 (B=4, 128/64 tokens) timed in full with 1 warm-up + 3 repetitions: see `protocol`",
+            "protocol": extra}
 
 
-def pmc_traffic(cfg_name, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, MI355X_MICROARCH.md HBM section); counters cannot be read from inside the benchmark process, so the
-    figure is only reported for the workload the passes were taken on, else null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if cfg_name != "cfg3" or batch != 16 or not os.path.exists(path):
-        return None
-    try:
-        with open(path) as f:
-            return round(json.load(f)["kernels"]["gemm_nt_mfma*"]["hbm_bytes_per_launch"])
-    except (KeyError, ValueError):
-        return None
+def kernel_src_sha16():
+    """Same stamp as tools/pmc_traffic.py: sha256 over csrc/*.hip and *.h."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(cfg_name, batch, family="gemm_nt_mfma*"):
+    """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    MI355X_MICROARCH.md HBM section).  Counters cannot be read from inside the benchmark process, so the figure comes from
+    the committed passes -- and only if they were taken on THESE kernel sources (kernel_src_sha16 stamp) and this workload;
+    otherwise null."""
+    import glob
+    stamp = kernel_src_sha16()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("kernel_src_sha16") != stamp or d.get("workload", "cfg3/16") != f"{cfg_name}/{batch}":
+                continue
+            return round(d["kernels"][family]["hbm_bytes_per_launch"])
+        except (KeyError, ValueError, OSError):
+            continue
+    return None
 
 
 def spawn_ranks(n: int) -> int:
@@ -352,7 +408,7 @@ def main():
                 trainer.evaluate(batch)
             torch.cuda.synchronize()
             out["config"]["forward_only_samples_per_s"] = round(B * 3 / (time.perf_counter() - t2), 2)
-            out["cpu_baseline"] = cpu_baseline(model, esm, llama, args.config, Tp, Tt, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(model, esm, llama, args.config, Tp, Tt, args.cpu_sample, args.cpu_cfg2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -19,7 +19,9 @@
  * unless named host_*.  Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*),
  * never allocates, never synchronises; buffers are owned by the caller (PyTorch's allocator in the
  * Python host).  Return value: P2T_OK or a negative code, text via p2t_last_error().
- * The library is re-entrant per stream; the only global state is the thread-local error string.
+ * The library is re-entrant per stream.  Global state: the thread-local error string; the measurement hooks
+ * (p2t_prof_*, mutex-guarded, off by default); the GEMM launch-form override (p2t_set_gemm_policy, one atomic word,
+ * default 0).  No environment variable is read.
  */
 #ifndef P2T_HIP_H
 #define P2T_HIP_H
@@ -60,6 +62,11 @@ size_t p2t_struct_size(int which);
  * 4 B nh T^2 d, halved when causal); it then resets the record list. */
 int p2t_prof_enable(int on);
 int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes);
+/* Launch-form override of the bf16 MFMA GEMM for experiments and tests (process-wide): 0 = measured default policy;
+ * 128 / 256 = force the tile height (per-tile kernels); 1 = no split-K tail; 2 = per-tile kernels only; 3 = persistent
+ * kernel with the split-K fix-up whenever possible; 4 = persistent, never the fix-up; 5 = persistent, partial round as
+ * 128-row halves.  Results are identical up to the fp32 summation order. */
+int p2t_set_gemm_policy(int policy);
 
 /* ---------------------------------------------------------------- synthetic data (bench / tests) */
 /* dst[i] = (int(hash24(i)) - 2^23) * scale23 + offset ; see p2t_hip/synth.py (bit-identical). */

@@ -1,4 +1,6 @@
 // GEMM and attention dispatch: argument checks, kernel choice (MFMA vs fp32-FMA), C entry points.
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -12,15 +14,20 @@ namespace p2t {
 // that kernel's own duration on the GPU; nothing synchronises until p2t_prof_collect.
 namespace {
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+// Process-global measurement state (the library's only mutable global besides the launch-policy word and the
+// thread-local error string): guarded by a mutex, off by default -- the unlocked fast path is one relaxed load.
 struct Prof {
-    bool on = false;
+    std::atomic<bool> on{false};
+    std::mutex mu;
     std::vector<ProfRec> pool;
     size_t used = 0;
 } g_prof;
 constexpr size_t kProfMax = 1 << 15;
 
 int prof_begin(hipStream_t s, int cls, double flops) {
-    if (!g_prof.on || g_prof.used >= kProfMax) return -1;
+    if (!g_prof.on.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    if (g_prof.used >= kProfMax) return -1;
     if (g_prof.used == g_prof.pool.size()) {
         ProfRec r{};
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
@@ -32,7 +39,9 @@ int prof_begin(hipStream_t s, int cls, double flops) {
     return (int)g_prof.used++;
 }
 void prof_end(hipStream_t s, int idx) {
-    if (idx >= 0) (void)hipEventRecord(g_prof.pool[idx].b, s);
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    (void)hipEventRecord(g_prof.pool[idx].b, s);
 }
 }  // namespace
 
@@ -106,13 +115,22 @@ int attention(const void* q, const void* k, const void* v, const uint8_t* key_ma
 using namespace p2t;
 
 extern "C" int p2t_prof_enable(int on) {
-    g_prof.on = on != 0;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    g_prof.on.store(on != 0, std::memory_order_relaxed);
     g_prof.used = 0;
+    return P2T_OK;
+}
+
+extern "C" int p2t_set_gemm_policy(int policy) {
+    P2T_REQUIRE(policy == 0 || policy == 1 || policy == 2 || policy == 3 || policy == 4 || policy == 5 || policy == 128 || policy == 256,
+                "p2t_set_gemm_policy: unknown policy %d", policy);
+    set_gemm_policy(policy);
     return P2T_OK;
 }
 
 extern "C" int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes) {
     P2T_REQUIRE(ms && launches && flops && n_classes >= 2, "p2t_prof_collect: bad arguments");
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     for (int c = 0; c < n_classes; ++c) { ms[c] = 0.0; launches[c] = 0; flops[c] = 0.0; }
     for (size_t i = 0; i < g_prof.used; ++i) {
         ProfRec& r = g_prof.pool[i];

@@ -19,6 +19,7 @@
 //   * 1-D grid with an XCD-aware, grouped tile order: the 8 XCDs get contiguous chunks of the tile list and
 //     consecutive tiles share activation row-panels (L2 reuse, technique T1).
 // Requirements: K % 64 == 0 (callers pad K with zeros), lda/ldw % 8 == 0, 16-byte aligned bases.
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -236,12 +237,18 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
         return;
     }
     if constexpr (MODE == TILE_CONSUME) {
-        // first K half: wait for the partner (dispatched earlier, so it is running or done), acquire, add its slab
+        // first K half: wait for the partner, acquire, add its slab.  Invariant that makes the wait finite: a producer
+        // has a LOWER block id than its consumer, never waits on anything, and hardware dispatches workgroups in id order,
+        // so by the time a consumer runs its producer has been dispatched (running or done) -- whatever else shares the
+        // chip (other streams' grids only delay it).  The spin is bounded all the same; giving up is LOUD: the time-out
+        // word stays set (sticky until the tower's next forward zeroes the header) and every consumer that sees it
+        // writes NaN tiles, so the loss of the step is NaN (the reference loop aborts on that, train_contrast.py:476-480)
+        // instead of a silently stale sum.
         if (threadIdx.x == 0) {
             unsigned spins = 0;
             while (__hip_atomic_load(fix->flag + fix_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fix->epoch) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 22)) {                  // ~ seconds: give up loudly instead of hanging the GPU
+                if (++spins > (1u << 22)) {                  // ~ seconds
                     __hip_atomic_store(fix->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -250,13 +257,15 @@ __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        const bool timed_out = __hip_atomic_load(fix->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        const float poison = timed_out ? __builtin_nanf("") : 0.f;
         const float4* slab = reinterpret_cast<const float4*>(fix->slab) + (int64_t)fix_tile * (MT * NT * 512);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 const float4 p = slab[(i * MT + j) * 512 + threadIdx.x];
-                acc[i][j][0] += p.x; acc[i][j][1] += p.y; acc[i][j][2] += p.z; acc[i][j][3] += p.w;
+                acc[i][j][0] += p.x + poison; acc[i][j][1] += p.y + poison; acc[i][j][2] += p.z + poison; acc[i][j][3] += p.w + poison;
             }
     }
 
@@ -473,7 +482,7 @@ __global__ void __launch_bounds__(512)
     }
     // Split-K fix-up of a partial last round (see gemm_nt_mfma_tail_kernel): n_items counts the whole rounds only; each of
     // the n_tail leftover tiles runs as two K halves on two blocks -- producers on blocks [0, n_tail) (they never wait),
-    // consumers on [n_tail, 2 n_tail).  All blocks of this grid are resident, so the consumer's bounded spin is safe.
+    // consumers on [n_tail, 2 n_tail): a producer has the lower block id and never waits (see gemm_tile, TILE_CONSUME).
     // half_tail: the same leftover tiles, each as two 128-row halves on two blocks over the whole K (no hand-off): the
     // partial round then costs one 128 x 256 tile (~0.62 of a tile time) instead of a whole one -- for K too short for
     // the split-K form to pay.
@@ -539,7 +548,25 @@ static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, in
 // rounds of 256-row tiles + the leftover rows as 128-row tiles) was tried against the 2.5-round N = 2560 GEMMs and
 // measured 5-13 % SLOWER than plain 256-row tiles, so it is not used.
 constexpr double kSmallTileCost = 0.625;
-constexpr int kCUs = 256;
+
+// Compute units of the current device (256 on MI355X; fewer on a partitioned one): the persistent grid is one block per
+// CU and the "round" arithmetic of the launch policy counts in CUs.
+static int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+// Launch-form override for experiments and tests (p2t_set_gemm_policy; 0 = the measured default policy).  An explicit API
+// call, deliberately not an environment variable: nothing outside the caller's control changes kernel selection.
+static std::atomic<int> g_gemm_policy{0};
+void set_gemm_policy(int policy) { g_gemm_policy.store(policy, std::memory_order_relaxed); }
 
 // Layout of the split-K fix-up workspace: [0, 1024) flag words, [1024, 1088) timeout word, [2048, ...) slabs.
 constexpr size_t kFixHeader = 2048, kFixSlab = 256 * 256 * sizeof(float);
@@ -549,10 +576,8 @@ size_t gemm_fix_header_bytes() { return kFixHeader; }
 template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                         const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes, unsigned fix_epoch, hipStream_t s) {
-    if (tile == 0) {                                       // experiments only: P2T_GEMM_TILE=128|256 forces a tile height,
-        const char* e = getenv("P2T_GEMM_TILE");           // 1 disables the split-K tail, 2 disables the persistent kernel
-        tile = e ? atoi(e) : 0;
-    }
+    if (tile == 0) tile = g_gemm_policy.load(std::memory_order_relaxed);   // 128 | 256: tile height; 1: no split-K tail; 2: no persistent kernel; 3 / 4 / 5 below
+    const int kCUs = cu_count();
     {
         // persistent kernel: shapes without edge tiles and at least one whole round of tiles.  tile: 0 / 3 = with the
         // split-K fix-up of a partial last round when it is worth it (3: whenever possible), 4 = never, 5 = the partial
@@ -574,14 +599,14 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
             // the fix-up tiles run un-overlapped after the tile loop (~50 us): it pays when half a tile time is well above that
             // (K = 10240: +7 %), not at K = 4096 (SwiGLU GEMM of the text tower, 3.5 rounds: -7 %)
             const bool worth = tile == 3 || ns >= 192;
-            if (tile != 4 && tile != 5 && fix_ws && rem > 0 && rem <= 128 && (ns & 7) == 0 && worth && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
+            if (tile != 4 && tile != 5 && fix_ws && rem > 0 && rem <= 128 && 2 * rem <= kCUs && (ns & 7) == 0 && worth && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
                 n_full = items - rem;
                 n_tail = rem;
                 fix.flag = (unsigned*)fix_ws;
                 fix.timeout = (unsigned*)((char*)fix_ws + 1024);
                 fix.slab = (float*)((char*)fix_ws + kFixHeader);
                 fix.epoch = fix_epoch;
-            } else if ((tile == 0 || tile == 5) && rem > 0 && rem <= 128) {
+            } else if ((tile == 0 || tile == 5) && rem > 0 && rem <= 128 && 2 * rem <= kCUs) {
                 // K too short for split-K to pay: the leftover tiles as 128-row halves, one per block (measured cold, as in
                 // a step: QKV 7.5 rounds -4.6 %, o-proj 2.5 rounds -3.7 %; FFN-down K = 10240 stays split-K: 787 vs 818 us)
                 n_full = items - rem;

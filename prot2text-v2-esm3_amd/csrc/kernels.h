@@ -33,6 +33,7 @@ int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, i
 int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                      int out_dtype, int epilogue, const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes,
                      unsigned fix_epoch, hipStream_t s);
+void set_gemm_policy(int policy);       // launch-form override of the MFMA GEMM (tests / experiments), 0 = default
 size_t gemm_fix_workspace_bytes();       // split-K tail fix-up workspace (flags + slabs); header must be zeroed once per
 size_t gemm_fix_header_bytes();          // sequence of launches that use distinct epochs
 // full dispatcher behind p2t_gemm_nt (gemm.hip)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "p2t_last_error": (C.c_char_p, []),
     "p2t_struct_size": (sz, [i32]),
     "p2t_prof_enable": (i32, [i32]),
+    "p2t_set_gemm_policy": (i32, [i32]),
     "p2t_prof_collect": (i32, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64), i32]),
     "p2t_fill_hash": (i32, [vp, i64, u64, u64, f32, f32, i32, vp]),
     "p2t_cast": (i32, [vp, i32, vp, i32, i64, vp]),

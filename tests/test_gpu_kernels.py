@@ -22,6 +22,14 @@ def ops():
     return _ops
 
 
+@pytest.fixture
+def gemm_policy():
+    """p2t_set_gemm_policy for one test (launch-form override of the MFMA GEMM), back to the default afterwards."""
+    from p2t_hip import _lib
+    yield lambda p: _lib.call("p2t_set_gemm_policy", int(p))
+    _lib.call("p2t_set_gemm_policy", 0)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_fill_hash_bit_exact(ops):
     from p2t_hip import synth
@@ -189,6 +197,9 @@ def test_qkv_rope_epilogue_vs_reference_arithmetic(ops, case, path):
 
 
 def test_gemm_argument_errors(ops):
+    from p2t_hip import _lib
+    with pytest.raises(ValueError):
+        _lib.call("p2t_set_gemm_policy", 7)
     a, w = torch.zeros((8, 64), device=dev()), torch.zeros((24, 64), device=dev())
     with pytest.raises(ValueError):
         ops.gemm_nt(a, w)                                   # N % 16 != 0
@@ -398,14 +409,14 @@ def test_clip_adamw(ops, max_norm):
 @pytest.mark.parametrize("shape", [(16384, 2560, 4096), (4096, 5376, 4096), (2048, 4096, 8192)])
 @pytest.mark.parametrize("path", ["persistent", "per_tile"])
 @pytest.mark.parametrize("epi", [EPI_STORE, EPI_RESID, EPI_GELU])
-def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
+def test_gemm_mfma_splitk_tail(ops, epi, path, shape, gemm_policy):
     """640 tiles = 2.5 rounds of the 256 CUs: with a fix-up workspace the last 128 tiles run as two concurrent K
     halves (producer slab -> consumer epilogue).  Must equal the plain kernel bit for bit in structure-independent
     terms (same fp32 sums up to the order of the two K halves) and the oracle; repeated launches reuse the flags.
     Both kernels that implement it: the persistent one (default for this shape) and the one-block-per-tile one."""
     # 2: per-tile kernels only; 3: persistent kernel with the fix-up whenever possible (the default policy only uses it
     # from K = 6144 up, where it pays)
-    monkeypatch.setenv("P2T_GEMM_TILE", "2" if path == "per_tile" else "3")
+    gemm_policy(2 if path == "per_tile" else 3)
     M, N, K = shape                 # 640 tiles = 2.5 rounds / 336 tiles = 1 round + 80 / 128 tiles, all split (long K)
     n_tail = ((M // 256) * (N // 256)) % 256
     a, w = bf16r(rnd(12, "s.a", (M, K), 1.0)), bf16r(rnd(12, "s.w", (N, K), 0.3))
@@ -420,17 +431,17 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, monkeypatch):
         assert rel(got[:, :N], ref) < (3e-6 if epi == EPI_RESID else 3e-3), epoch
     flags = ws[:2048].view(torch.int32).cpu().numpy()
     assert (flags[:n_tail] == 3).all() and not flags[n_tail:128].any() and flags[256] == 0   # every tail tile published; no time-out
-    monkeypatch.setenv("P2T_GEMM_TILE", "2")                      # plain per-tile kernel, no workspace
+    gemm_policy(2)                                                # plain per-tile kernel, no workspace
     plain = to_np(ops.gemm_nt(ad, wd, bd, epilogue=epi, out=to_dev(resid) if epi == EPI_RESID else None, use_mfma=1))
     assert rel(got[:, :N], plain[:, :N]) < (1e-6 if epi == EPI_RESID else 2e-3)
 
 
 @pytest.mark.parametrize("tile", ["0", "3", "4", "5"])
-def test_gemm_persistent_forms_fuzz(ops, tile, monkeypatch):
+def test_gemm_persistent_forms_fuzz(ops, tile, gemm_policy):
     """Random whole-tile shapes through the persistent kernel (default policy / split-K fix-up forced / no fix-up /
     128-row halves for the partial round) against
     the exact fp32-FMA kernel on the same bf16 operands: any stale LDS read or mis-counted wait shows up as a wrong tile."""
-    monkeypatch.setenv("P2T_GEMM_TILE", tile)
+    gemm_policy(int(tile))
     rng = np.random.default_rng(int(tile) + 7)
     ws = ops.gemm_fix_workspace(dev())
     epoch = 0

@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
-from p2t_hip import ops  # noqa: E402
+from p2t_hip import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -51,12 +51,9 @@ def bench_gemm():
         res = []
         for env, fn in (("2", lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1)), ("2", with_tail),
                         ("4", with_tail), ("3", with_tail), (None, with_tail)):
-            if env is None:
-                os.environ.pop("P2T_GEMM_TILE", None)
-            else:
-                os.environ["P2T_GEMM_TILE"] = env
+            _lib.call("p2t_set_gemm_policy", int(env or 0))
             res.append(timeit(fn))
-        os.environ.pop("P2T_GEMM_TILE", None)
+        _lib.call("p2t_set_gemm_policy", 0)
         fl = 2.0 * M * N * K / 1e9
         print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: TF/s per-tile {fl / res[0]:7.1f} | per-tile+splitK {fl / res[1]:7.1f} | "
               f"persistent {fl / res[2]:7.1f} | persistent+splitK {fl / res[3]:7.1f} | default {fl / res[4]:7.1f} ({res[4]:.3f} ms)", flush=True)
@@ -76,10 +73,7 @@ def bench_cold():
         fl = 2.0 * M * N * K / 1e9
         res = []
         for env in ("2", "4", "3", "5", None):
-            if env is None:
-                os.environ.pop("P2T_GEMM_TILE", None)
-            else:
-                os.environ["P2T_GEMM_TILE"] = env
+            _lib.call("p2t_set_gemm_policy", int(env or 0))
             tot = 0.0
             for i in range(6):
                 flush.fill_(i)
@@ -92,7 +86,7 @@ def bench_cold():
                 if i > 0:
                     tot += s0.elapsed_time(e0)
             res.append(tot / 5)
-        os.environ.pop("P2T_GEMM_TILE", None)
+        _lib.call("p2t_set_gemm_policy", 0)
         print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
               f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | persistent+half-tiles {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f} | "
               f"default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f}", flush=True)

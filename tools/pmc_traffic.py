@@ -22,7 +22,23 @@ import re
 import sys
 from collections import defaultdict
 
-FAMILIES = {"gemm_nt_mfma": "gemm_nt_mfma*", "attn_mfma_kernel": "attn_mfma_kernel", "norm_kernel": "norm_kernel"}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_src_sha16():
+    """Stamp of the kernel sources the counters were taken on (bench.py recomputes it and reports `traffic: null` when the
+    sources have changed since): sha256 over csrc/*.hip and *.h in name order."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+FAMILIES = {"gemm_nt_mfma": "gemm_nt_mfma*", "gemm_nt_fp8": "gemm_nt_fp8*", "attn_mfma_kernel": "attn_mfma_kernel", "norm_kernel": "norm_kernel"}
 
 
 def family(name):
@@ -57,7 +73,7 @@ def main():
                 merged[fam][cname] = {"avg": total / max(n, 1), "launches": n}
     out = {"source": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline --no-batch64-check; aggregated by tools/pmc_traffic.py",
-           "label": label,
+           "label": label, "kernel_src_sha16": kernel_src_sha16(),
            "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE "
                     "reports half of wide coalesced reads; Infinity-Cache hits included)",
            "kernels": {}}
