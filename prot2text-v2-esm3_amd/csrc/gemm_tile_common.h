@@ -1,0 +1,65 @@
+// Pieces shared by the bf16 (gemm_mfma.hip) and fp8 (gemm_fp8.hip) MFMA GEMM kernels: both use 16x16 accumulator tiles in
+// the same wave layout (8 waves as 2 (M) x 4 (N), W rows permuted at staging), so the tile order and the epilogue -- which
+// only sees the C/D fragment, dtype independent on gfx950 -- are common.
+#pragma once
+#include "common.h"
+#include "epilogue.h"
+
+namespace p2t {
+
+// (tm, tn) of work item `id` out of `n_items`: the 8 XCDs get contiguous chunks (bijective for any count),
+// inside a chunk GM row-tiles are walked column-major so neighbouring CUs share activation panels.
+__device__ __forceinline__ void tile_coords(int id, int n_items, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q8 = n_items >> 3, r8 = n_items & 7, xcd = id & 7;
+    const int swz_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    constexpr int GM = 4;
+    const int band = swz_id / (GM * tiles_n), first_m = band * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_band = swz_id - band * GM * tiles_n;
+    tm = first_m + in_band % gm;
+    tn = in_band / gm;
+}
+
+// Epilogue of one tile: lane owns row m, columns nb .. nb+7 (n-tiles 0,1) and nb+32 .. nb+39 (n-tiles 2,3).
+// INTERIOR: the tile lies fully inside the output (no row / column checks, one basic block).  Read-modify-write
+// epilogues (Epi::kRmw) then fetch their operand for four rows at a time before the first add, so the HBM latency of
+// the residual read is paid twice per tile instead of once per row.
+template <int MT, typename Epi, bool INTERIOR = false>
+__device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[4][MT], const EpiParams& ep, int64_t M, int N, int n_cover,
+                                              int64_t m0, int n0, int wm, int wn, int fr, int kg) {
+    const int nb = n0 + wn * 64 + kg * 8;
+    if (!INTERIOR && nb >= n_cover) return;
+    float b0[8], b1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b0[e] = b1[e] = 0.f;
+    if (ep.bias) {
+        if (INTERIOR || nb < N) loadW<8>(ep.bias + nb, b0);
+        if (INTERIOR || nb + 32 < N) loadW<8>(ep.bias + nb + 32, b1);
+    }
+    if constexpr (INTERIOR && Epi::kRmw && MT % 4 == 0) {
+#pragma unroll
+        for (int jb = 0; jb < MT; jb += 4) {
+            float r0[4][8], r1[4][8];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) Epi::template fetch2<8>(ep, m0 + wm * MT * 16 + (jb + jj) * 16 + fr, nb, r0[jj], r1[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = jb + jj;
+                const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+                const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+                Epi::template apply2_fetched<8>(ep, m0 + wm * MT * 16 + j * 16 + fr, nb, v0, v1, b0, b1, r0[jj], r1[jj]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
+            if (!INTERIOR && m >= M) continue;
+            const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+            const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+            Epi::template apply2<8>(ep, m, nb, v0, v1, b0, b1);
+        }
+    }
+}
+
+}  // namespace p2t

@@ -137,10 +137,17 @@ class ContrastiveCollater:
 def sort_batch_by_length(batch: Dict[str, Any], descending: bool = True) -> Dict[str, Any]:
     """Reorder the pairs of a collated (host) batch by protein length and add `protein_lengths` (list of ints, host),
     `description_lengths` (host ints) and `description_order` (int64 tensor: rows by falling description length).
-    Every per-pair entry (tensors with leading dimension B, lists of length B) is permuted the same way."""
+    Every per-pair entry (tensors with leading dimension B, lists of length B) is permuted the same way.
+    The lengths feed ContrastiveTrainer(trim_padding=True), which cuts `ids[:, :T_s]`: that is only valid for RIGHT-padded
+    rows (the contract of the contrastive batch, dataset/dataloader.py:113-123,139-149), so both masks are checked to be
+    prefixes here, on the host; a left-padded batch (dataset/dataloader_derived.py:142-147 can build one) is refused."""
     mask = batch["protein_attention_mask"]
     if mask.is_cuda:
         raise ValueError("sort_batch_by_length works on the host batch (before the H2D copy)")
+    for key in ("protein_attention_mask", "description_attention_mask"):
+        m = batch.get(key)
+        if m is not None and m.dim() == 2 and m.shape[1] > 1 and not bool((m[:, :-1] >= m[:, 1:]).all()):
+            raise ValueError(f"{key} is not right-padded (a row has a 1 after a 0): trimming by length would cut valid tokens")
     lengths = mask.sum(dim=1)
     order = torch.argsort(lengths, descending=descending, stable=True)
     B = int(mask.shape[0])

@@ -160,3 +160,17 @@ def test_prefetcher_with_length_sort_transform_keeps_host_lengths():
         lens = b["description_lengths"]
         assert [lens[j] for j in b["description_order"].tolist()] == sorted(lens, reverse=True)
     assert list(DevicePrefetcher([], "cpu")) == []
+
+
+def test_sort_batch_by_length_refuses_left_padding():
+    """trim_padding slices ids[:, :T_s]: only valid for right-padded rows, verified on the host (dataloader_derived.py:142-147
+    can produce left-padded descriptions)."""
+    import torch
+    from p2t_hip.data import sort_batch_by_length
+    ok = {"protein_input_ids": torch.zeros((2, 4), dtype=torch.int64), "protein_attention_mask": torch.tensor([[1, 1, 1, 0], [1, 0, 0, 0]]),
+          "description_input_ids": torch.zeros((2, 3), dtype=torch.int64), "description_attention_mask": torch.tensor([[1, 1, 0], [1, 1, 1]])}
+    assert sort_batch_by_length(ok)["protein_lengths"] == [3, 1]
+    for key, bad in (("protein_attention_mask", torch.tensor([[0, 1, 1, 1], [1, 0, 0, 0]])),
+                     ("description_attention_mask", torch.tensor([[1, 0, 1], [1, 1, 1]]))):
+        with pytest.raises(ValueError, match="right-padded"):
+            sort_batch_by_length(dict(ok, **{key: bad}))
