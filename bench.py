@@ -36,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0           # dense fp8 (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4: 2x the bf16 rate, same guide)
 
 
 def parse():
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 | cfg4 (SURVEY.md section 8 table)")
+    ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 | cfg4 | cfg5 = fp8 tower GEMMs (SURVEY.md section 8 table)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--segments", type=int, default=1, help="contrastive_num_segments")
     ap.add_argument("--eval-mode", action="store_true", help="no adapter dropout (default: train mode, p=0.3)")
@@ -260,8 +261,10 @@ def main():
     B = args.batch or B
     esm, llama = specs.esm_spec(esm_name), specs.llama_spec(llama_name)
     ad = specs.adapter_spec(esm, llama)
-    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-    model = P.Esm2LlamaInstructForCausalLM.from_specs(esm, llama, ad, dtype=dtype, device=dev, seed=0)
+    fp8 = dtype_name == "fp8"
+    dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
+    model = P.Esm2LlamaInstructForCausalLM.from_specs(esm, llama, ad, dtype=dtype, device=dev, seed=0,
+                                                      gemm_dtype="fp8" if fp8 else "model")
     model.esm_encoder.requires_grad_(False)
     model.llama_decoder.requires_grad_(False)
     trainer = P.ContrastiveTrainer(model, num_segments=args.segments, train_mode=not args.eval_mode, global_negatives=True,
@@ -289,10 +292,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     # per-kernel event times (synchronises the recorded events; outside the timed region)
-    ms = (ctypes.c_double * 2)()
-    cnt = (ctypes.c_int64 * 2)()
-    fl = (ctypes.c_double * 2)()
-    _lib.call("p2t_prof_collect", ms, cnt, fl, 2)
+    ms = (ctypes.c_double * 3)()
+    cnt = (ctypes.c_int64 * 3)()
+    fl = (ctypes.c_double * 3)()
+    _lib.call("p2t_prof_collect", ms, cnt, fl, 3)
     _lib.call("p2t_prof_enable", 0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -309,13 +312,22 @@ def main():
         He, Le = esm.hidden_size, esm.num_hidden_layers
         attn_flops = Le * 4 * Tp * Tp * He + min(16, llama.num_hidden_layers) * 2 * (Tt + 1) * Tt * llama.hidden_size
         gemm_flops_step = (f["total"] - attn_flops) * B
-        launches_step = cnt[0] / max(ev_steps, 1)
-        avg_ms = ms[0] / max(cnt[0], 1)
-        achieved = (gemm_flops_step / max(launches_step, 1)) / (avg_ms * 1e-3) / 1e12 if cnt[0] else 0.0
+        if fp8:
+            # dominant kernel: the fp8 MFMA GEMM (the tower projections); the adapter's bf16 GEMMs are a separate, small family.
+            # Its algorithmic FLOPs are the towers' linear layers = HIP-event class 2's own tally (2 M N K per launch).
+            dom = 2
+            gemm_flops_step = fl[2] / max(ev_steps, 1)
+        else:
+            dom = 0
+        launches_step = cnt[dom] / max(ev_steps, 1)
+        avg_ms = ms[dom] / max(cnt[dom], 1)
+        achieved = (gemm_flops_step / max(launches_step, 1)) / (avg_ms * 1e-3) / 1e12 if cnt[dom] else 0.0
         out = {
             "metric": "contrastive-step samples/sec (protein-text pairs)", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8-e4m3 weights and GEMM operands (per-row E8M0 scales, fp8 MFMA), bf16 activations" if fp8 else dtype_name,
+            "data": "synthetic",
             "config": {"workload": f"{args.config}: {esm_name} + {llama_name} (text layers 1-16), per-GPU batch {B} x {Tp} residues / "
                                    f"{B} x {Tt} text tokens, readout mix, InfoNCE tau=0.05, adapter fwd+bwd + clip + AdamW, "
                                    f"{'train mode (dropout 0.3)' if not args.eval_mode else 'eval mode'}, segments {args.segments}",
@@ -326,14 +338,21 @@ def main():
                        "algorithmic_tflop_per_sample": round(f["total"] / 1e12, 4),
                        "step_tflops_per_gpu": round(step_tflops, 1), "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                        "loss": round(loss_val, 5)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: persistent / per-tile / split-K-tail variants, all epilogues)",
-                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(args.config, B),
+            "roofline": {"bound": "mfma",
+                         "kernel": ("gemm_nt_fp8_kernel (e4m3 16x16x128 block-scaled MFMA GEMM, all epilogues)" if fp8 else
+                                    "gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: persistent / per-tile / split-K-tail variants, all epilogues)"),
+                         "achieved": round(achieved, 1), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), 4),
+                         "frac_of_bf16_peak": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": pmc_traffic(args.config, B, "gemm_nt_fp8*" if fp8 else "gemm_nt_mfma*"),
                          "launches_per_step": round(launches_step, 1), "avg_launch_ms": round(avg_ms, 4),
-                         "gemm_ms_per_step": round(ms[0] / max(ev_steps, 1), 3), "attention_ms_per_step": round(ms[1] / max(ev_steps, 1), 3),
+                         "gemm_ms_per_step": round(ms[dom] / max(ev_steps, 1), 3), "attention_ms_per_step": round(ms[1] / max(ev_steps, 1), 3),
+                         "bf16_gemm_ms_per_step": round(ms[0] / max(ev_steps, 1), 3),
                          "event_steps": ev_steps,
                          "attention_tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1)},
         }
+        if fp8:
+            out["config"]["step_frac_of_fp8_peak"] = round(step_tflops / PEAK_FP8_TFLOPS, 4)
         if world == 1 and not args.no_batch64_check and B != 64 and args.config in ("cfg3", "cfg4"):
             # BASELINE.json north_star quotes its >= 40 % target "at batch 64 x 1024 residues": measured here, after
             # and outside the timed region that produces `value`, on the same model.
@@ -351,7 +370,7 @@ def main():
             tf64 = f["total"] * 64 / dt64 / 1e12
             out["config"]["batch64_check"] = {"samples_per_s": round(64 / dt64, 2), "ms_per_step": round(dt64 * 1e3, 2),
                                               "step_tflops": round(tf64, 1), "frac_of_bf16_peak": round(tf64 / PEAK_BF16_TFLOPS, 4)}
-        if world == 1 and not args.no_batch64_check and args.config in ("cfg3", "cfg4"):
+        if world == 1 and not args.no_batch64_check and args.config in ("cfg3", "cfg4", "cfg5"):
             # Ragged workload: 64 pairs with protein lengths from a clipped log-normal (median ~315
             # residues, the shape of UniProt lengths; crop at 1024), once as the padded 64 x T_max step and once
             # length-sorted (data.sort_batch_by_length) and cut into segments that each run at their own longest length

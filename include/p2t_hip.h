@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define P2T_VERSION 100
+#define P2T_VERSION 101
 
 enum { P2T_OK = 0, P2T_ERR_ARG = -1, P2T_ERR_HIP = -2, P2T_ERR_UNSUPPORTED = -3 };
-enum { P2T_F32 = 0, P2T_BF16 = 1 };                       /* storage dtype of weights / activations */
+enum { P2T_F32 = 0, P2T_BF16 = 1,                         /* storage dtype of weights / activations */
+       P2T_FP8 = 2 };                                      /* GEMM operands only: OCP e4m3fn bytes + one E8M0 scale byte per row */
 enum { P2T_READOUT_LAST = 0, P2T_READOUT_MEAN = 1, P2T_READOUT_STD = 2, P2T_READOUT_MIX = 3 };
 enum {                                                     /* GEMM epilogues (p2t_gemm_nt) */
     P2T_EPI_STORE = 0,      /* C = acc + bias                                   */
@@ -56,7 +57,8 @@ const char* p2t_last_error(void);
 size_t p2t_struct_size(int which);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
-/* When enabled, every MFMA GEMM (class 0) and MFMA attention (class 1) launch is bracketed by HIP events on its
+/* When enabled, every bf16 MFMA GEMM (class 0), MFMA attention (class 1) and fp8 MFMA GEMM (class 2; only reported
+ * when n_classes >= 3) launch is bracketed by HIP events on its
  * own launch stream.  p2t_prof_collect synchronises those events (the only host sync in the library) and returns,
  * per class, the summed kernel time in ms, the launch count and the algorithmic FLOPs (GEMM: 2 M N K; attention:
  * 4 B nh T^2 d, halved when causal); it then resets the record list. */
@@ -93,6 +95,25 @@ int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
                 void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
                 int use_mfma, void* fix_ws, size_t fix_ws_bytes, unsigned fix_epoch, p2t_stream stream);
 size_t p2t_gemm_fix_workspace_bytes(void);
+/* ---- fp8 GEMM operands (BASELINE.json configs[4]: "fp8 weights, CDNA4 fp8 MFMA") ----
+ * Row-wise quantisation: x `dtype` (F32 / BF16) [rows, ld_x] -> q: OCP e4m3fn bytes [rows, ld_q] (columns cols..ld_q-1 zero;
+ * ld_q a multiple of 8, of 128 when q feeds p2t_gemm_nt_fp8) and scale: one E8M0 byte per row, E = 127 + e with 2^e the
+ * smallest power of two such that amax(row) / 2^e <= 448; q = e4m3_rne(x * 2^-e).  An all-zero row gets E = 127. */
+int p2t_quant_rows_fp8(const void* x, int dtype, int64_t ld_x, int64_t rows, int64_t cols, void* q, int64_t ld_q,
+                       uint8_t* scale, p2t_stream stream);
+/* torch.nn.LayerNorm / LlamaRMSNorm of the f32 stream written directly in that format (no bf16 intermediate). */
+int p2t_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* q, int64_t ld_q,
+                      uint8_t* scale, int64_t rows, int64_t cols, p2t_stream stream);
+int p2t_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale,
+                    int64_t rows, int64_t cols, p2t_stream stream);
+/* C[M,N] = (A8 * 2^(a_scale-127))[M,K] * (W8 * 2^(w_scale-127))[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (both scales
+ * applied by the instruction), fp32 accumulate, the epilogues of p2t_gemm_nt (all but GELU_BWD).  A8 / W8: e4m3 bytes,
+ * row strides lda / ldw in BYTES (multiples of 16), K % 128 == 0 with the padding zeroed; a_scale [M], w_scale [N] E8M0
+ * bytes.  tile: 0 auto, 128 / 256 rows. */
+int p2t_gemm_nt_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
+                    const float* bias, void* out, int64_t ldc, void* z, int64_t M, int64_t N, int64_t K, int out_dtype,
+                    int epilogue, int accumulate, int tile, p2t_stream stream);
+
 /* The QKV projection as the towers launch it for head_dim 64 / 128 (P2T_EPI_QKV_ROPE): acc + bias, query * q_scale
  * BEFORE the rotation (HF EsmSelfAttention.forward, modeling_esm.py:345,362-378: q_scale = head_dim^-1/2 and SDPA scale 1;
  * Llama: q_scale 1, no bias, modeling_llama.py:254-259), rotate-half rotary with the table built from inv_freq
@@ -136,7 +157,9 @@ typedef struct {
     int32_t n_layers, hidden, ffn, heads, head_dim, vocab;
     int32_t pad_id, mask_id, token_dropout, emb_layer_norm_before;
     float layer_norm_eps, rope_theta;
-    int32_t dtype;                       /* P2T_F32 | P2T_BF16 */
+    int32_t dtype;                       /* P2T_F32 | P2T_BF16: activations, attention, vectors */
+    int32_t gemm_fp8;                    /* 1: the four projections run on the fp8 MFMA kernel (needs dtype BF16): the
+                                            matrices are e4m3 bytes with one E8M0 scale per row, see p2t_esm2_layer */
 } p2t_esm2_config;
 
 /* Packed per-layer weights (device).  Matrices are `dtype`, row-major [N][ld], ld = K rounded up
@@ -148,6 +171,9 @@ typedef struct {
     const void* fc1_w;  const float* fc1_b;          /* intermediate.dense  */
     const void* fc2_w;  const float* fc2_b;          /* output.dense        */
     const float* ln2_w; const float* ln2_b;          /* layer LayerNorm     */
+    /* gemm_fp8 only: the four matrices above are then e4m3 bytes, row-major [N][ld], ld = K rounded up to 128 (zero
+     * padded), quantised with p2t_quant_rows_fp8, and these are their E8M0 row scales [N] */
+    const uint8_t* qkv_ws; const uint8_t* o_ws; const uint8_t* fc1_ws; const uint8_t* fc2_ws;
 } p2t_esm2_layer;
 
 typedef struct {
@@ -174,6 +200,7 @@ typedef struct {
     float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
     int32_t rope_original_max_pos;
     int32_t dtype;
+    int32_t gemm_fp8;                    /* as p2t_esm2_config.gemm_fp8 */
 } p2t_llama_config;
 
 /* qkv_w rows: q (heads*d), k (kv*d), v (kv*d); for head_dim 128 the 128 rows of EVERY head are stored in the order
@@ -184,6 +211,7 @@ typedef struct {
     const void* qkv_w; const void* o_w; const void* gu_w; const void* down_w;
     const float* ln1_w;                              /* input_layernorm */
     const float* ln2_w;                              /* post_attention_layernorm */
+    const uint8_t* qkv_ws; const uint8_t* o_ws; const uint8_t* gu_ws; const uint8_t* down_ws;   /* gemm_fp8: E8M0 row scales */
 } p2t_llama_layer;
 
 typedef struct {

@@ -41,17 +41,62 @@ def _bf16(x: np.ndarray) -> np.ndarray:
     return r.astype(np.uint32).view(F32).reshape(x.shape)
 
 
+def e4m3_round(x: np.ndarray) -> np.ndarray:
+    """OCP e4m3fn rounding of f32 values (4 exponent bits, bias 7, 3 mantissa bits, subnormals of 2^-9, largest finite
+    448, no infinities), round-to-nearest-even -- what v_cvt_pk_fp8_f32 does on gfx950 and torch.float8_e4m3fn on the
+    CPU (tests/test_fp8_host.py pins this function on the latter).  |x| <= 448 is the caller's business (scaled rows)."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    a = np.abs(x)
+    _, ex = np.frexp(a)                                  # a = m 2^ex, m in [0.5, 1): floor(log2 a) = ex - 1
+    e = np.maximum(ex.astype(np.int32) - 1, -6)          # below 2^-6 the spacing stays that of the subnormals
+    quantum = np.ldexp(F32(1.0), e - 3).astype(F32)
+    r = (np.rint(a / quantum) * quantum).astype(F32)     # rint: ties to even; both operations are exact in f32
+    r = np.minimum(r, F32(448.0))
+    return np.copysign(r, x).astype(F32)
+
+
+def e8m0_of_amax(amax: np.ndarray) -> np.ndarray:
+    """Biased E8M0 exponent of a row's power-of-two scale: the smallest 2^e with amax / 2^e <= 448, by the same integer
+    rule on the f32 bits as csrc/quant.hip (e = exponent(amax) - 8 + [mantissa > 0.75]); 127 for an all-zero row."""
+    u = np.ascontiguousarray(amax, dtype=F32).view(np.uint32)
+    ea = ((u >> np.uint32(23)) & np.uint32(0xFF)).astype(np.int32) - 127
+    e = ea - 8 + ((u & np.uint32(0x7FFFFF)) > np.uint32(0x600000)).astype(np.int32)
+    E = np.clip(e + 127, 1, 254)
+    return np.where(amax > 0, E, 127).astype(np.uint8)
+
+
+def quant_rows_e4m3(x: np.ndarray):
+    """Row-wise fp8 quantisation of a GEMM operand (BASELINE.json configs[4]): -> (dequantised values f32 [rows, cols],
+    E8M0 scale byte per row, the e4m3 values before rescaling).  x / 2^e is exact, so e4m3_round is the only rounding."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    E = e8m0_of_amax(np.abs(x).max(axis=-1))
+    scale = np.ldexp(F32(1.0), E.astype(np.int32) - 127).astype(F32)[..., None]
+    q = e4m3_round(x / scale)
+    return (q * scale).astype(F32), E, q
+
+
 class Precision:
+    """identity (fp32 oracle); "bf16": bf16 rounding where the HIP bf16 path stores bf16; "fp8": the same, plus e4m3
+    row-quantised operands (weights per output channel, activations per token) in the tower GEMMs -- `g` is applied to
+    the two operands of every tower projection, `q` to everything the bf16 path rounds."""
+
     def __init__(self, kind: str = "f32"):
-        assert kind in ("f32", "bf16")
+        assert kind in ("f32", "bf16", "fp8")
         self.kind = kind
 
     def q(self, x):           # "quantise a stored activation / weight"
         return x if self.kind == "f32" else _bf16(x)
 
+    def g(self, x):           # "quantise a tower-GEMM operand" (rows of a 2-D array)
+        return quant_rows_e4m3(x)[0] if self.kind == "fp8" else x
+
+    def a(self, x):           # a norm output feeding a projection: bf16 storage, or straight to fp8 (no bf16 in between)
+        return x if self.kind == "fp8" else self.q(x)
+
 
 FP32 = Precision("f32")
 BF16 = Precision("bf16")
+FP8 = Precision("fp8")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -175,13 +220,13 @@ def esm2_layer(spec, W, i, x, key_bias, cos, sin, prec: Precision = FP32, prefix
     B, T, H = x.shape
     nh, d = spec.num_attention_heads, spec.head_dim
     p = f"{prefix}encoder.layer.{i}."
-    q_ = prec.q
-    h = q_(layer_norm(x, W[p + "attention.LayerNorm.weight"], W[p + "attention.LayerNorm.bias"],
-                      spec.layer_norm_eps))
-    h2 = h.reshape(B * T, H)
+    q_, g_ = prec.q, prec.g
+    h = prec.a(layer_norm(x, W[p + "attention.LayerNorm.weight"], W[p + "attention.LayerNorm.bias"],
+                          spec.layer_norm_eps))
+    h2 = g_(h.reshape(B * T, H))
 
-    def lin(name, inp):
-        return inp @ q_(W[p + name + ".weight"]).T + W[p + name + ".bias"]
+    def lin(name, inp):           # inp: already a GEMM operand (g_ applied by the caller, once per activation)
+        return inp @ g_(q_(W[p + name + ".weight"])).T + W[p + name + ".bias"]
 
     q = lin("attention.self.query", h2).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
     k = lin("attention.self.key", h2).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
@@ -190,10 +235,10 @@ def esm2_layer(spec, W, i, x, key_bias, cos, sin, prec: Precision = FP32, prefix
     q = q * cos + rotate_half(q) * sin                                    # ESM:74-79 (fp32)
     k = k * cos + rotate_half(k) * sin
     q, k, v = q_(q), q_(k), q_(v)
-    o = q_(attention_heads(q, k, v, key_bias, 1.0, prec).reshape(B * T, H))     # ESM:310-317, scale 1.0
+    o = g_(q_(attention_heads(q, k, v, key_bias, 1.0, prec).reshape(B * T, H)))     # ESM:310-317, scale 1.0
     x = x + lin("attention.output.dense", o).reshape(B, T, H)               # ESM:399-409
-    h = q_(layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], spec.layer_norm_eps))
-    f = q_(gelu_erf(lin("intermediate.dense", h.reshape(B * T, H))))         # ESM:442-450
+    h = prec.a(layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], spec.layer_norm_eps))
+    f = g_(q_(gelu_erf(lin("intermediate.dense", g_(h.reshape(B * T, H))))))   # ESM:442-450
     x = x + lin("output.dense", f).reshape(B, T, H)                          # ESM:453-463
     return x.astype(F32)
 
@@ -276,21 +321,24 @@ def llama_layer(spec, W, i, x, bias, cos, sin, prec: Precision = FP32, prefix=""
     B, T, H = x.shape
     nh, nkv, d = spec.num_attention_heads, spec.num_key_value_heads, spec.head_dim
     p = f"{prefix}model.layers.{i}."
-    q_ = prec.q
-    h = q_(rms_norm(x, W[p + "input_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H)
-    q = (h @ q_(W[p + "self_attn.q_proj.weight"]).T).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
-    k = (h @ q_(W[p + "self_attn.k_proj.weight"]).T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
-    v = (h @ q_(W[p + "self_attn.v_proj.weight"]).T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+    q_, g_ = prec.q, prec.g
+
+    def wq(name):                 # weights: model-dtype storage, then (fp8 mode) one e4m3 scale per output channel
+        return g_(q_(W[p + name + ".weight"]))
+    h = g_(prec.a(rms_norm(x, W[p + "input_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H))
+    q = (h @ wq("self_attn.q_proj").T).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+    k = (h @ wq("self_attn.k_proj").T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+    v = (h @ wq("self_attn.v_proj").T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
     q = q * cos + rotate_half(q) * sin
     k = k * cos + rotate_half(k) * sin
     q, k, v = q_(q), q_(k), q_(v)
-    o = q_(attention_heads(q, k, v, bias, d ** -0.5, prec).reshape(B * T, nh * d))
-    x = x + (o @ q_(W[p + "self_attn.o_proj.weight"]).T).reshape(B, T, H)
-    h = q_(rms_norm(x, W[p + "post_attention_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H)
-    g = h @ q_(W[p + "mlp.gate_proj.weight"]).T
-    u = h @ q_(W[p + "mlp.up_proj.weight"]).T
-    a = q_((g / (F32(1.0) + np.exp(-g, dtype=F32))) * u)                  # SiLU(g) * u, LLAMA:174-176
-    x = x + (a @ q_(W[p + "mlp.down_proj.weight"]).T).reshape(B, T, H)
+    o = g_(q_(attention_heads(q, k, v, bias, d ** -0.5, prec).reshape(B * T, nh * d)))
+    x = x + (o @ wq("self_attn.o_proj").T).reshape(B, T, H)
+    h = g_(prec.a(rms_norm(x, W[p + "post_attention_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H))
+    g = h @ wq("mlp.gate_proj").T
+    u = h @ wq("mlp.up_proj").T
+    a = g_(q_((g / (F32(1.0) + np.exp(-g, dtype=F32))) * u))              # SiLU(g) * u, LLAMA:174-176
+    x = x + (a @ wq("mlp.down_proj").T).reshape(B, T, H)
     return x.astype(F32)
 
 

@@ -56,6 +56,11 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     P2T_REQUIRE(!rope || (a.cs && a.q && a.k && a.v && a.seq > 0 && (a.head_dim == 64 || a.head_dim == 128) &&
                           a.N == (int64_t)(a.nh + 2 * a.nkv) * a.head_dim && a.M % a.seq == 0),
                 "gemm_nt: EPI_QKV_ROPE needs head_dim 64 or 128 outputs, the rotary table and M = B * seq");
+    if (a.dtype == P2T_FP8)
+        P2T_REQUIRE(a.a_scale && a.w_scale && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && (uintptr_t)a.A % 16 == 0 &&
+                        (uintptr_t)a.W % 16 == 0 && a.epilogue != P2T_EPI_GELU_BWD,
+                    "gemm_nt (fp8): needs both row-scale arrays, K %% 128 == 0 (zero padded), 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)",
+                    (long long)a.K, (long long)a.lda, (long long)a.ldw);
     P2T_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0 && a.lda >= a.K && a.ldw >= a.K,
                 "gemm_nt: K and the row strides must be multiples of 4 (K=%lld lda=%lld ldw=%lld ldc=%lld)", (long long)a.K,
                 (long long)a.lda, (long long)a.ldw, (long long)a.ldc);
@@ -78,6 +83,13 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     ep.drop_seed = a.drop_seed;
     ep.cs = a.cs; ep.q = a.q; ep.k = a.k; ep.v = a.v; ep.seq = a.seq; ep.nh = a.nh; ep.nkv = a.nkv; ep.q_scale = a.q_scale; ep.head_dim = a.head_dim;
 
+    if (a.dtype == P2T_FP8) {
+        const int pi = prof_begin(s, 2, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+        const int rc = launch_gemm_fp8(a.A, a.lda, a.a_scale, a.W, a.ldw, a.w_scale, a.M, (int)a.N, (int)a.K, n_cover, out_dtype, a.epilogue, ep,
+                                       a.tile, s);
+        prof_end(s, pi);
+        return rc;
+    }
     const bool aligned = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0);
     const bool can_mfma = a.dtype == P2T_BF16 && a.K % 64 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && aligned;
     if (a.use_mfma == 1 && !can_mfma) {
@@ -129,7 +141,7 @@ extern "C" int p2t_set_gemm_policy(int policy) {
 }
 
 extern "C" int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes) {
-    P2T_REQUIRE(ms && launches && flops && n_classes >= 2, "p2t_prof_collect: bad arguments");
+    P2T_REQUIRE(ms && launches && flops && n_classes >= 2 && n_classes <= 8, "p2t_prof_collect: bad arguments");
     std::lock_guard<std::mutex> lock(g_prof.mu);
     for (int c = 0; c < n_classes; ++c) { ms[c] = 0.0; launches[c] = 0; flops[c] = 0.0; }
     for (size_t i = 0; i < g_prof.used; ++i) {
@@ -152,6 +164,14 @@ extern "C" int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
 }
 
 extern "C" size_t p2t_gemm_fix_workspace_bytes(void) { return gemm_fix_workspace_bytes(); }
+
+extern "C" int p2t_gemm_nt_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
+                               const float* bias, void* out, int64_t ldc, void* z, int64_t M, int64_t N, int64_t K, int out_dtype,
+                               int epilogue, int accumulate, int tile, p2t_stream stream) {
+    GemmArgs a{A, lda, W, ldw, bias, out, ldc, z, M, N, K, P2T_FP8, out_dtype, epilogue, accumulate, 1, -1, 0.f, 0, tile};
+    a.a_scale = a_scale; a.w_scale = w_scale;
+    return gemm_nt(a, (hipStream_t)stream);
+}
 
 extern "C" int p2t_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t K,
                                  int dtype, const float* inv_freq, float* cos_sin_scratch, void* q, void* k, void* v, int seq,

@@ -1,0 +1,239 @@
+// fp8 (OCP e4m3) MFMA GEMM for gfx950:  C[M,N] = (A8 . 2^ea)[M,K] * (W8 . 2^ew)[N,K]^T, fp32 accumulate, fused epilogue.
+//
+// Operands are e4m3 bytes with ONE power-of-two scale per row (E8M0 byte: a token's activations, an output channel's
+// weights; quant.hip); the block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 multiplies at twice the bf16
+// rate and applies both scales itself (its scale operands, constant along K here).  Lane maps of the instruction, found
+// with one-hot operands on the hardware (tools/mx_probe2.hip, profiles/r02_mx_probe.log):
+//   operand registers 0..3 of lane (r = lane & 15, g = lane >> 4) hold K bytes 16 g .. 16 g + 15 of row r, registers 4..7
+//   hold K bytes 64 + 16 g .. 64 + 16 g + 15 -- two K = 64 halves, each laid out exactly like the bf16 16x16x32 operand
+//   (16 bytes per lane, lane group g = k chunk g); the scale byte of lane 16 b + r applies to (row r, K block b of 32).
+// So the LDS image, the LDS-DMA staging, the source-side bank swizzle and the W-row permutation of the bf16 kernel
+// (gemm_mfma.hip) carry over byte for byte: a "stage" is (BM + 256) rows x 64 bytes = 64 K elements, and one K step of
+// 128 consumes two stages (low / high half of the operand registers).  What differs is the register budget: an operand
+// fragment is 8 registers, so 8 + 4 fragments (96) + 128 accumulators leave no room for double buffering; fragments are
+// reloaded in place as soon as their last MFMA of the step has issued (W fragment i after row i of the 4 x 8 MFMA grid,
+// activation fragment j after MFMA (3, j)) from the OTHER pair of ring slots, and the ring is two K steps deep:
+//   top of step s:  wait own DMAs (step s+1) + own LDS reads, barrier  ->  DMA of step s+2 into the slots of step s,
+//   interleaved with the 32 MFMAs of step s and the 24 fragment reads of step s+1.
+// Per-tile launch form (one block per tile, XCD-aware grouped tile order), epilogues shared with the bf16 kernel.
+// Requirements: K % 128 == 0 (producers pad K with zero bytes), lda / ldw % 16 == 0, 16-byte aligned bases.
+#include <type_traits>
+
+#include "common.h"
+#include "epilogue.h"
+#include "gemm_tile_common.h"
+#include "kernels.h"
+
+namespace p2t {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int OA, int OB>
+__device__ __forceinline__ f32x4 mfma_fp8(const v8i& a, const v8i& b, const f32x4& c, int sa, int sb) {
+    // cbsz = blgp = 0: both operands e4m3; op_sel picks the byte of the scale registers
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, sa, OB, sb);
+}
+
+template <int MT, typename Epi>
+__global__ void __launch_bounds__(512)
+    gemm_nt_fp8_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ a_scale, const uint8_t* __restrict__ W,
+                       int64_t ldw, const uint8_t* __restrict__ w_scale, int64_t M, int N, int K, int tiles_m, int tiles_n, int n_cover,
+                       EpiParams ep) {
+    constexpr int WN = 4, NT = 4, BM = 2 * MT * 16;
+    constexpr int AI = BM / 128;                            // activation DMA pieces per wave per stage (1 KiB each)
+    constexpr int SLOT = (BM + 256) * 64;                   // bytes per stage (64 K bytes of every row)
+    constexpr int NP = 2 * (AI + 2);                        // DMA pieces per wave per K step
+    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * 256;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / WN, wn = w % WN;
+    const int ns = K >> 7;                                  // K steps of 128
+
+    // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row = lane >> 2, 16-byte chunk = lane & 3, swizzled) ----
+    const int schunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    const char* a_base = (const char*)A + m0 * lda;         // uniform: tile origin; lane offsets below are the same for every stage
+    const char* w_base = (const char*)W + (int64_t)n0 * ldw;
+    uint32_t a_voff[AI], w_voff[2];
+#pragma unroll
+    for (int t = 0; t < AI; ++t) {
+        int64_t am = m0 + (w * AI + t) * 16 + (lane >> 2);
+        am = (am < M ? am : M - 1) - m0;                    // rows past the edge re-read the last row (results discarded)
+        a_voff[t] = (uint32_t)(am * lda + schunk * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int R = (w * 2 + t) * 16 + (lane >> 2), r = R & 63;
+        const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);     // permuted weight row
+        int wr = n0 + (R & ~63) + nl;
+        wr = (wr < N ? wr : N - 1) - n0;
+        w_voff[t] = (uint32_t)((int64_t)wr * ldw + schunk * 16);
+    }
+    // LDS DMA as inline asm in the saddr form (see gemm_mfma.hip: the builtin makes LLVM drain every counted wait)
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto piece = [&](auto which, int s) {                   // DMA piece `which` (0 .. NP-1) of K step s
+        constexpr int P = decltype(which)::value;
+        constexpr int H = P / (AI + 2), Q = P % (AI + 2);   // stage half, piece within the stage: Q < AI activation, else weight
+        const int stage = 2 * s + H;
+        const char* sb = (Q < AI ? a_base : w_base) + (int64_t)stage * 64;
+        const uint32_t vo = Q < AI ? a_voff[Q < AI ? Q : 0] : w_voff[Q < AI ? 0 : Q - AI];
+        const uint32_t lds = lds0 + (stage & 3) * SLOT + (Q < AI ? (w * AI + Q) * 1024 : BM * 64 + (w * 2 + (Q - AI)) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(lds) : "memory");
+    };
+    auto issue_all = [&](int s) {
+        piece(std::integral_constant<int, 0>{}, s); piece(std::integral_constant<int, 1>{}, s);
+        piece(std::integral_constant<int, 2>{}, s); piece(std::integral_constant<int, 3>{}, s);
+        piece(std::integral_constant<int, 4>{}, s); piece(std::integral_constant<int, 5>{}, s);
+        if constexpr (NP == 8) { piece(std::integral_constant<int, 6>{}, s); piece(std::integral_constant<int, 7>{}, s); }
+    };
+
+    // ---- fragment read offsets (as the bf16 kernel) ----
+    const int fr = lane & 15, kg = lane >> 4;
+    const int sw = (kg ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4;
+    const int x_off = (wm * MT * 16 + fr) * 64 + sw;
+    const int w_off = BM * 64 + (wn * NT * 16 + fr) * 64 + sw;
+    auto frag = [&](int s, int off) -> v8i {                // low half from stage 2 s, high half from stage 2 s + 1
+        const v4i lo = *reinterpret_cast<const v4i*>(smem + ((2 * s) & 3) * SLOT + off);
+        const v4i hi = *reinterpret_cast<const v4i*>(smem + ((2 * s + 1) & 3) * SLOT + off);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    // ---- prologue: DMA of K steps 0 and 1, then the row scales (E8M0 bytes, one per operand row, packed per fragment) ----
+    issue_all(0);
+    if (ns > 1) issue_all(1);
+    int sx[MT / 4 > 0 ? MT / 4 : 1], sw8 = 0;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
+        m = m < M ? m : M - 1;
+        const int e = a_scale[m];
+        if ((j & 3) == 0) sx[j >> 2] = e; else sx[j >> 2] |= e << (8 * (j & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int r = i * 16 + fr;
+        const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
+        int n = n0 + wn * 64 + nl;
+        n = n < N ? n : N - 1;
+        sw8 |= (int)w_scale[n] << (8 * i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every prologue DMA (and the scale bytes) landed
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8i X[MT], Wf[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Wf[i] = frag(0, w_off + i * 1024);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) X[j] = frag(0, x_off + j * 1024);
+
+    // One K step.  MORE: a step s + 1 exists (reload the fragments); ISSUE: a step s + 2 exists (start its DMA).  Both are
+    // compile-time so the steady-state body is branch-free; the last two steps are peeled below.
+    auto step = [&](auto more_c, auto issue_c, int s) {
+        constexpr bool MORE = decltype(more_c)::value, ISSUE = decltype(issue_c)::value;
+        // own fragment reads of step s complete, own DMAs of step s+1 landed; after the barrier: every wave's are, so the
+        // slots of step s may be overwritten and the slots of step s+1 may be read
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        auto row = [&](auto ii) {
+            constexpr int I = decltype(ii)::value;
+            auto two = [&](auto jj) {                       // MFMAs (I, J), (I, J + 1)
+                constexpr int J = decltype(jj)::value;
+                acc[I][J] = mfma_fp8<I, J & 3>(Wf[I], X[J], acc[I][J], sw8, sx[J >> 2]);
+                acc[I][J + 1] = mfma_fp8<I, (J + 1) & 3>(Wf[I], X[J + 1], acc[I][J + 1], sw8, sx[(J + 1) >> 2]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto dma2 = [&](auto pp) {                      // DMA piece pp of step s + 2
+                constexpr int P = decltype(pp)::value;
+                if constexpr (ISSUE && P < NP) piece(std::integral_constant<int, P>{}, s + 2);
+            };
+            auto reloadx = [&](auto jj) {
+                constexpr int J = decltype(jj)::value;
+                if constexpr (MORE && I == NT - 1) {        // last use of the activation fragments J, J + 1 was just issued
+                    X[J] = frag(s + 1, x_off + J * 1024);
+                    X[J + 1] = frag(s + 1, x_off + (J + 1) * 1024);
+                }
+            };
+            two(std::integral_constant<int, 0>{});
+            dma2(std::integral_constant<int, 2 * I>{});
+            reloadx(std::integral_constant<int, 0>{});
+            two(std::integral_constant<int, 2>{});
+            dma2(std::integral_constant<int, 2 * I + 1>{});
+            reloadx(std::integral_constant<int, 2>{});
+            if constexpr (MT >= 8) {
+                two(std::integral_constant<int, 4>{});
+                reloadx(std::integral_constant<int, 4>{});
+                two(std::integral_constant<int, 6>{});
+                reloadx(std::integral_constant<int, 6>{});
+            }
+            if constexpr (MORE) Wf[I] = frag(s + 1, w_off + I * 1024);   // row I done: its W fragment is free
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        row(std::integral_constant<int, 0>{});
+        row(std::integral_constant<int, 1>{});
+        row(std::integral_constant<int, 2>{});
+        row(std::integral_constant<int, 3>{});
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int s = 0;
+    for (; s + 2 < ns; ++s) step(T{}, T{}, s);
+    if (s + 1 < ns) { step(T{}, F{}, s); ++s; }
+    step(F{}, F{}, s);
+    tile_epilogue<MT, Epi>(acc, ep, M, N, n_cover, m0, n0, wm, wn, fr, kg);
+}
+
+template <int MT, typename Epi>
+static int launch_cfg8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M,
+                       int N, int K, int n_cover, const EpiParams& ep, hipStream_t s) {
+    constexpr int BM = 2 * MT * 16;
+    const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(n_cover, 256);
+    gemm_nt_fp8_kernel<MT, Epi><<<dim3((unsigned)(tiles_m * tiles_n)), 512, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale,
+                                                                                   M, N, K, tiles_m, tiles_n, n_cover, ep);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+template <typename Epi>
+static int launch_shape8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M,
+                         int N, int K, int n_cover, const EpiParams& ep, int tile, hipStream_t s) {
+    // 256-row tiles unless 128-row tiles fill the chip better (same rule as the bf16 per-tile kernels)
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
+    const double cost256 = (double)ceil_div(tm256 * tn, cus);
+    const double cost128 = (double)ceil_div(tm128 * tn, cus) * 0.625 * 1.08;
+    if (tile == 256 || (tile != 128 && cost256 <= cost128)) return launch_cfg8<8, Epi>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, ep, s);
+    return launch_cfg8<4, Epi>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, ep, s);
+}
+
+int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
+                    int K, int n_cover, int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s) {
+    const bool ob = out_dtype == P2T_BF16;
+#define P2T_FP8_CASE(E) return launch_shape8<E>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, ep, tile, s)
+    switch (epilogue) {
+        case P2T_EPI_STORE: if (ob) P2T_FP8_CASE(EpiStore<bf16_t>); else P2T_FP8_CASE(EpiStore<float>);
+        case P2T_EPI_GELU: if (ob) P2T_FP8_CASE(EpiGelu<bf16_t>); else P2T_FP8_CASE(EpiGelu<float>);
+        case P2T_EPI_RESID: P2T_FP8_CASE(EpiResid);
+        case P2T_EPI_SWIGLU: if (ob) P2T_FP8_CASE(EpiSwiglu<bf16_t>); else P2T_FP8_CASE(EpiSwiglu<float>);
+        case P2T_EPI_STORE_F32: P2T_FP8_CASE(EpiF32);
+        case P2T_EPI_QKV_ROPE: if (ob) P2T_FP8_CASE(EpiQkvRope<bf16_t>); else P2T_FP8_CASE(EpiQkvRope<float>);
+    }
+#undef P2T_FP8_CASE
+    set_error("gemm (fp8): unsupported epilogue %d", epilogue);
+    return P2T_ERR_ARG;
+}
+
+}  // namespace p2t

@@ -33,6 +33,15 @@ int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, i
 int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                      int out_dtype, int epilogue, const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes,
                      unsigned fix_epoch, hipStream_t s);
+// fp8 path (quant.hip, gemm_fp8.hip)
+int launch_quant_rows(const void* x, int dtype, int64_t ld_x, int64_t rows, int64_t cols, void* q, int64_t ld_q, uint8_t* scale,
+                      hipStream_t s);
+int launch_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* q, int64_t ld_q,
+                         uint8_t* scale, int64_t rows, int64_t cols, hipStream_t s);
+int launch_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale, int64_t rows,
+                       int64_t cols, hipStream_t s);
+int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
+                    int K, int n_cover, int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s);
 void set_gemm_policy(int policy);       // launch-form override of the MFMA GEMM (tests / experiments), 0 = default
 size_t gemm_fix_workspace_bytes();       // split-K tail fix-up workspace (flags + slabs); header must be zeroed once per
 size_t gemm_fix_header_bytes();          // sequence of launches that use distinct epochs
@@ -48,6 +57,8 @@ struct GemmArgs {
     int seq = 0, nh = 0, nkv = 0; float q_scale = 1.f; int head_dim = 64;
     // optional split-K tail fix-up (MFMA kernel, 256-row tiles): workspace + an epoch unique since its header was zeroed
     void* fix_ws = nullptr; size_t fix_bytes = 0; unsigned fix_epoch = 0;
+    // dtype == P2T_FP8: A and W are e4m3 bytes (row strides in bytes), one E8M0 scale byte per row of each
+    const uint8_t* a_scale = nullptr; const uint8_t* w_scale = nullptr;
 };
 int gemm_nt(const GemmArgs& a, hipStream_t s);
 

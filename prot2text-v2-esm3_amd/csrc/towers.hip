@@ -15,6 +15,8 @@ namespace {
 struct EsmBuffers {
     uint8_t* key_mask; int32_t* kv_info; float* emb_scale; float* inv_freq; float* cs;
     float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* ffn; void* fix;
+    // gemm_fp8: e4m3 copies of the GEMM operands (row stride = K rounded up to 128 bytes) + one E8M0 scale per row
+    uint8_t* hq; uint8_t* hs; uint8_t* aoq; uint8_t* aos; uint8_t* ffnq; uint8_t* ffns;
 };
 
 size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b) {
@@ -38,6 +40,13 @@ size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b
     t.ao = a.take(e * (size_t)M * Hp);
     t.ffn = a.take(e * (size_t)M * Fp);
     t.fix = a.take(gemm_fix_workspace_bytes());
+    t.hq = t.hs = t.aoq = t.aos = t.ffnq = t.ffns = nullptr;
+    if (c->gemm_fp8) {
+        const int64_t Hq = round_up(H, 128), Fq = round_up(F, 128);
+        t.hq = (uint8_t*)a.take((size_t)M * Hq);   t.hs = (uint8_t*)a.take((size_t)M);
+        t.aoq = (uint8_t*)a.take((size_t)M * Hq);  t.aos = (uint8_t*)a.take((size_t)M);
+        t.ffnq = (uint8_t*)a.take((size_t)M * Fq); t.ffns = (uint8_t*)a.take((size_t)M);
+    }
     if (b) *b = t;
     return a.off + 256;
 }
@@ -45,6 +54,7 @@ size_t esm_plan(const p2t_esm2_config* c, int B, int T, Arena* ar, EsmBuffers* b
 struct LlamaBuffers {
     uint8_t* key_mask; int32_t* kv_info; float* inv_freq; float* cs;
     float* x; void* h; void* qkv; void* q; void* k; void* v; void* ao; void* act; void* fix;
+    uint8_t* hq; uint8_t* hs; uint8_t* aoq; uint8_t* aos; uint8_t* actq; uint8_t* acts;      // gemm_fp8 (see EsmBuffers)
 };
 
 size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffers* b) {
@@ -68,6 +78,13 @@ size_t llama_plan(const p2t_llama_config* c, int B, int T, Arena* ar, LlamaBuffe
     t.ao = a.take(e * (size_t)M * QO);
     t.act = a.take(e * (size_t)M * Fp);
     t.fix = a.take(gemm_fix_workspace_bytes());
+    t.hq = t.hs = t.aoq = t.aos = t.actq = t.acts = nullptr;
+    if (c->gemm_fp8) {
+        const int64_t Hq = round_up(H, 128), Fq = round_up(F, 128), QOq = round_up((int64_t)nh * d, 128);
+        t.hq = (uint8_t*)a.take((size_t)M * Hq);    t.hs = (uint8_t*)a.take((size_t)M);
+        t.aoq = (uint8_t*)a.take((size_t)M * QOq);  t.aos = (uint8_t*)a.take((size_t)M);
+        t.actq = (uint8_t*)a.take((size_t)M * Fq);  t.acts = (uint8_t*)a.take((size_t)M);
+    }
     if (b) *b = t;
     return a.off + 256;
 }
@@ -86,6 +103,7 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
     P2T_REQUIRE(c->hidden == c->heads * c->head_dim && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 16 == 0,
                 "p2t_esm2_forward: unsupported shape hidden=%d heads=%d head_dim=%d ffn=%d", c->hidden, c->heads, c->head_dim, c->ffn);
     P2T_REQUIRE(ld_out >= c->hidden && ld_out % 4 == 0, "p2t_esm2_forward: ld_out");
+    P2T_REQUIRE(!c->gemm_fp8 || c->dtype == P2T_BF16, "p2t_esm2_forward: gemm_fp8 needs bf16 activations (dtype = P2T_BF16)");
     P2T_REQUIRE(w->layers && w->word_emb && w->final_ln_w && w->final_ln_b, "p2t_esm2_forward: missing weights");
     P2T_REQUIRE(workspace_bytes >= p2t_esm2_workspace_bytes(c, B, T), "p2t_esm2_forward: workspace too small (%zu < %zu)",
                 workspace_bytes, p2t_esm2_workspace_bytes(c, B, T));
@@ -115,7 +133,42 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
     P2T_CHECK_HIP(hipMemsetAsync(b.fix, 0, gemm_fix_header_bytes(), s));      // split-K tail flags; epochs below are unique
     unsigned epoch = 0;
     auto with_fix = [&](GemmArgs& g) { g.fix_ws = b.fix; g.fix_bytes = gemm_fix_workspace_bytes(); g.fix_epoch = ++epoch; };
-    for (int l = 0; l < c->n_layers; ++l) {
+    const int64_t Hq = round_up(H, 128), Fq = round_up(F, 128);
+    for (int l = 0; c->gemm_fp8 && l < c->n_layers; ++l) {
+        // fp8 GEMMs (BASELINE.json configs[4]): the same layer, operands e4m3 with a power-of-two scale per row.  The
+        // LayerNorms write their output directly in that format; the attention output and the GELU output are produced
+        // in bf16 (attention reads bf16 q/k/v; GELU rows span many tiles) and quantised by one streaming pass each.
+        const p2t_esm2_layer& L = w->layers[l];
+        P2T_REQUIRE(L.qkv_ws && L.o_ws && L.fc1_ws && L.fc2_ws, "p2t_esm2_forward: gemm_fp8 needs the row scales of layer %d", l);
+        auto fp8 = [&](const void* A, int64_t lda, const uint8_t* as, const void* W, const uint8_t* ws, const float* bias, void* out, int64_t ldc,
+                       int64_t N, int64_t K, int out_dtype, int epi) {
+            GemmArgs g{A, lda, W, K, bias, out, ldc, nullptr, M, N, K, P2T_FP8, out_dtype, epi, 0, 1, -1, 0.f, 0, 0};
+            g.a_scale = as; g.w_scale = ws;
+            return g;
+        };
+        P2T_TRY(launch_layernorm_fp8(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        if (d == 64) {
+            GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, L.qkv_b, nullptr, 0, 3 * H, Hq, dt, P2T_EPI_QKV_ROPE);
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nh; g1.q_scale = q_scale;
+            P2T_TRY(gemm_nt(g1, s));
+        } else {
+            GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, L.qkv_b, b.qkv, 3 * H, 3 * H, Hq, dt, P2T_EPI_STORE);
+            g1.n_zero = (int)(3 * H);
+            P2T_TRY(gemm_nt(g1, s));
+            P2T_TRY(launch_qkv_post(b.qkv, 3 * H, b.cs, b.q, b.k, b.v, B, T, nh, nh, d, dp, q_scale, dt, s));
+        }
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, s));
+        P2T_TRY(launch_quant_rows(b.ao, dt, Hp, M, H, b.aoq, Hq, b.aos, s));
+        GemmArgs g2 = fp8(b.aoq, Hq, b.aos, L.o_w, L.o_ws, L.o_b, b.x, H, H, Hq, P2T_F32, P2T_EPI_RESID);
+        P2T_TRY(gemm_nt(g2, s));
+        P2T_TRY(launch_layernorm_fp8(b.x, H, L.ln2_w, L.ln2_b, c->layer_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        GemmArgs g3 = fp8(b.hq, Hq, b.hs, L.fc1_w, L.fc1_ws, L.fc1_b, b.ffn, Fp, F, Hq, dt, P2T_EPI_GELU);
+        P2T_TRY(gemm_nt(g3, s));
+        P2T_TRY(launch_quant_rows(b.ffn, dt, Fp, M, F, b.ffnq, Fq, b.ffns, s));
+        GemmArgs g4 = fp8(b.ffnq, Fq, b.ffns, L.fc2_w, L.fc2_ws, L.fc2_b, b.x, H, H, Fq, P2T_F32, P2T_EPI_RESID);
+        P2T_TRY(gemm_nt(g4, s));
+    }
+    for (int l = 0; !c->gemm_fp8 && l < c->n_layers; ++l) {
         const p2t_esm2_layer& L = w->layers[l];
         P2T_TRY(launch_layernorm(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.h, Hp, M, H, dt, s));
         if (d == 64) {
@@ -187,7 +240,40 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
     P2T_CHECK_HIP(hipMemsetAsync(b.fix, 0, gemm_fix_header_bytes(), s));      // split-K flags; epochs below are unique
     unsigned epoch = 0;
     auto with_fix = [&](GemmArgs& g) { g.fix_ws = b.fix; g.fix_bytes = gemm_fix_workspace_bytes(); g.fix_epoch = ++epoch; };
-    for (int l = 0; l < k; ++l) {
+    P2T_REQUIRE(!c->gemm_fp8 || dt == P2T_BF16, "p2t_llama_hidden_forward: gemm_fp8 needs bf16 activations (dtype = P2T_BF16)");
+    const int64_t Hq = round_up(H, 128), Fq = round_up(F, 128), QOq = round_up((int64_t)nh * d, 128);
+    for (int l = 0; c->gemm_fp8 && l < k; ++l) {
+        const p2t_llama_layer& L = w->layers[l];
+        P2T_REQUIRE(L.qkv_ws && L.o_ws && L.gu_ws && L.down_ws, "p2t_llama_hidden_forward: gemm_fp8 needs the row scales of layer %d", l);
+        auto fp8 = [&](const void* A, int64_t lda, const uint8_t* as, const void* W, const uint8_t* ws, void* out, int64_t ldc, int64_t N,
+                       int64_t K, int out_dtype, int epi) {
+            GemmArgs g{A, lda, W, K, nullptr, out, ldc, nullptr, M, N, K, P2T_FP8, out_dtype, epi, 0, 1, -1, 0.f, 0, 0};
+            g.a_scale = as; g.w_scale = ws;
+            return g;
+        };
+        P2T_TRY(launch_rmsnorm_fp8(b.x, H, L.ln1_w, c->rms_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        if (d == 64 || d == 128) {
+            GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, nullptr, 0, NQKV, Hq, dt, P2T_EPI_QKV_ROPE);
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f; g1.head_dim = d;
+            P2T_TRY(gemm_nt(g1, s));
+        } else {
+            GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, b.qkv, NQKV, NQKV, Hq, dt, P2T_EPI_STORE);
+            g1.n_zero = (int)NQKV;
+            P2T_TRY(gemm_nt(g1, s));
+            P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, 1.0f, dt, s));
+        }
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, s));
+        P2T_TRY(launch_quant_rows(b.ao, dt, QO, M, (int64_t)nh * d, b.aoq, QOq, b.aos, s));
+        GemmArgs g2 = fp8(b.aoq, QOq, b.aos, L.o_w, L.o_ws, b.x, H, H, QOq, P2T_F32, P2T_EPI_RESID);
+        P2T_TRY(gemm_nt(g2, s));
+        P2T_TRY(launch_rmsnorm_fp8(b.x, H, L.ln2_w, c->rms_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        GemmArgs g3 = fp8(b.hq, Hq, b.hs, L.gu_w, L.gu_ws, b.act, Fp, 2 * F, Hq, dt, P2T_EPI_SWIGLU);
+        P2T_TRY(gemm_nt(g3, s));
+        P2T_TRY(launch_quant_rows(b.act, dt, Fp, M, F, b.actq, Fq, b.acts, s));
+        GemmArgs g4 = fp8(b.actq, Fq, b.acts, L.down_w, L.down_ws, b.x, H, H, Fq, P2T_F32, P2T_EPI_RESID);
+        P2T_TRY(gemm_nt(g4, s));
+    }
+    for (int l = 0; !c->gemm_fp8 && l < k; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
         if (d == 64 || d == 128) {

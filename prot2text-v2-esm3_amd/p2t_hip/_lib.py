@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P2T_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("P2T_HIP_LIB") or os.path.join(_HERE, "lib", "libp2t_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 READOUT = {"last": 0, "mean": 1, "std": 2, "mix": 3}
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD = range(6)
 
@@ -34,12 +34,12 @@ vp, i32, i64, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.
 class EsmConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layers", "hidden", "ffn", "heads", "head_dim", "vocab", "pad_id", "mask_id",
                                         "token_dropout", "emb_layer_norm_before")] + \
-               [("layer_norm_eps", f32), ("rope_theta", f32), ("dtype", C.c_int32)]
+               [("layer_norm_eps", f32), ("rope_theta", f32), ("dtype", C.c_int32), ("gemm_fp8", C.c_int32)]
 
 
 class EsmLayerC(C.Structure):
     _fields_ = [(n, vp) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_w", "ln1_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                                  "ln2_w", "ln2_b")]
+                                  "ln2_w", "ln2_b", "qkv_ws", "o_ws", "fc1_ws", "fc2_ws")]
 
 
 class EsmWeightsC(C.Structure):
@@ -51,11 +51,11 @@ class LlamaConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layers", "hidden", "ffn", "heads", "kv_heads", "head_dim", "vocab")] + \
                [("rms_norm_eps", f32), ("rope_theta", f32), ("rope_llama3", C.c_int32), ("rope_factor", f32),
                 ("rope_low_freq_factor", f32), ("rope_high_freq_factor", f32), ("rope_original_max_pos", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("gemm_fp8", C.c_int32)]
 
 
 class LlamaLayerC(C.Structure):
-    _fields_ = [(n, vp) for n in ("qkv_w", "o_w", "gu_w", "down_w", "ln1_w", "ln2_w")]
+    _fields_ = [(n, vp) for n in ("qkv_w", "o_w", "gu_w", "down_w", "ln1_w", "ln2_w", "qkv_ws", "o_ws", "gu_ws", "down_ws")]
 
 
 class LlamaWeightsC(C.Structure):
@@ -92,6 +92,10 @@ SIGNATURES = {
     "p2t_transpose": (i32, [vp, i64, i64, i64, vp, i64, i32, vp]),
     "p2t_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32, vp, sz, C.c_uint, vp]),
     "p2t_gemm_fix_workspace_bytes": (sz, []),
+    "p2t_quant_rows_fp8": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, vp]),
+    "p2t_layernorm_fp8": (i32, [vp, i64, vp, vp, f32, vp, i64, vp, i64, i64, vp]),
+    "p2t_rmsnorm_fp8": (i32, [vp, i64, vp, f32, vp, i64, vp, i64, i64, vp]),
+    "p2t_gemm_nt_fp8": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, vp]),
     "p2t_gemm_qkv_rope": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, sz,
                                 C.c_uint, vp]),
     "p2t_layernorm": (i32, [vp, i64, vp, vp, f32, vp, i64, i64, i64, i32, vp]),

@@ -80,6 +80,13 @@ def _pad_cols(w: torch.Tensor, ld: int, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+def _quant_fp8(w: torch.Tensor, k: int):
+    """Packed [N, ld] weight matrix (model dtype) -> (e4m3 bytes [N, round_up(k, 128)], E8M0 scale byte per output channel)."""
+    if w.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("fp8 GEMM weights are quantised from bf16 / f32 masters")
+    return ops.quant_rows_fp8(w.contiguous(), cols=k, ld_q=round_up(k, 128))
+
+
 def _f32(v: torch.Tensor) -> torch.Tensor:
     v = v.detach()
     return v if v.dtype == torch.float32 and v.is_contiguous() else v.float().contiguous()
@@ -129,6 +136,7 @@ class EsmEncoder(nn.Module):
         self.rotary_embeddings.register_buffer("inv_freq", inv.to(device))
         _init_tree(self)
         self._engine = None
+        self.gemm_fp8 = False            # True: the four projections of every layer run on the fp8 MFMA kernel
         self._ws = _Workspace()
         self._register_load_state_dict_pre_hook(self._remap_legacy_inv_freq)
         self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_engine())
@@ -167,6 +175,9 @@ class EsmEncoder(nn.Module):
                      fc1_w=_pad_cols(P[p + "intermediate.dense.weight"], Hp, dt), fc1_b=_f32(P[p + "intermediate.dense.bias"]),
                      fc2_w=_pad_cols(P[p + "output.dense.weight"], Fp, dt), fc2_b=_f32(P[p + "output.dense.bias"]),
                      ln2_w=_f32(P[p + "LayerNorm.weight"]), ln2_b=_f32(P[p + "LayerNorm.bias"]))
+            if self.gemm_fp8:           # e4m3 bytes + one E8M0 scale per output channel (include/p2t_hip.h, p2t_esm2_layer)
+                for name, kdim in (("qkv", H), ("o", H), ("fc1", H), ("fc2", F)):
+                    t[name + "_w"], t[name + "_ws"] = _quant_fp8(t[name + "_w"], kdim)
             keep.append(t)
             for k, v in t.items():
                 setattr(layers[i], k, v.data_ptr())
@@ -180,7 +191,10 @@ class EsmEncoder(nn.Module):
         cfg = _lib.EsmConfigC(n_layers=s.num_hidden_layers, hidden=H, ffn=F, heads=s.num_attention_heads,
                               head_dim=s.head_dim, vocab=s.vocab_size, pad_id=s.pad_token_id, mask_id=s.mask_token_id,
                               token_dropout=int(s.token_dropout), emb_layer_norm_before=int(s.emb_layer_norm_before),
-                              layer_norm_eps=s.layer_norm_eps, rope_theta=s.rope_theta, dtype=ops.dt_of(dt))
+                              layer_norm_eps=s.layer_norm_eps, rope_theta=s.rope_theta, dtype=ops.dt_of(dt),
+                              gemm_fp8=int(self.gemm_fp8))
+        if self.gemm_fp8 and dt != torch.bfloat16:
+            raise ValueError("fp8 GEMMs need a bf16 model (activations and attention stay bf16)")
         self._engine = dict(cfg=cfg, w=w, layers=layers, keep=keep, Hp=Hp)
         return self._engine
 
@@ -379,6 +393,7 @@ class LlamaTextModel(nn.Module):
         super().__init__()
         self.spec = spec
         self._engine, self._ws = None, _Workspace()
+        self.gemm_fp8 = False
         self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_engine())
 
     @property
@@ -406,6 +421,9 @@ class LlamaTextModel(nn.Module):
             t = dict(qkv_w=_pad_cols(qkv, Hp, dt), o_w=_pad_cols(P[p + "self_attn.o_proj.weight"], QO, dt),
                      gu_w=_pad_cols(gu, Hp, dt), down_w=_pad_cols(P[p + "mlp.down_proj.weight"], Fp, dt),
                      ln1_w=_f32(P[p + "input_layernorm.weight"]), ln2_w=_f32(P[p + "post_attention_layernorm.weight"]))
+            if self.gemm_fp8:
+                for name, kdim in (("qkv", H), ("o", s.num_attention_heads * d), ("gu", H), ("down", F)):
+                    t[name + "_w"], t[name + "_ws"] = _quant_fp8(t[name + "_w"], kdim)
             keep.append(t)
             for k, v in t.items():
                 setattr(layers[i], k, v.data_ptr())
@@ -419,7 +437,10 @@ class LlamaTextModel(nn.Module):
                                 rms_norm_eps=s.rms_norm_eps, rope_theta=s.rope_theta,
                                 rope_llama3=int(s.rope_type == "llama3"), rope_factor=s.rope_factor,
                                 rope_low_freq_factor=s.rope_low_freq_factor, rope_high_freq_factor=s.rope_high_freq_factor,
-                                rope_original_max_pos=s.rope_original_max_position_embeddings, dtype=ops.dt_of(dt))
+                                rope_original_max_pos=s.rope_original_max_position_embeddings, dtype=ops.dt_of(dt),
+                                gemm_fp8=int(self.gemm_fp8))
+        if self.gemm_fp8 and dt != torch.bfloat16:
+            raise ValueError("fp8 GEMMs need a bf16 model (activations and attention stay bf16)")
         self._engine = dict(cfg=cfg, w=w, layers=layers, keep=keep, n=n_layers)
         return self._engine
 
@@ -615,7 +636,7 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
     # ---- synthetic construction (bench / tests: no checkpoints exist offline) ----
     @classmethod
     def from_specs(cls, esm: specs.EsmSpec, llama: specs.LlamaSpec, adapter: specs.AdapterSpec, dtype=torch.bfloat16,
-                   device="cuda", seed: Optional[int] = 0, adapter_dtype=None):
+                   device="cuda", seed: Optional[int] = 0, adapter_dtype=None, gemm_dtype: str = "model"):
         model = cls(esm_encoder=EsmEncoder(esm_config_from_spec(esm), dtype, device),
                     adapter=ModalityAdapter(ModalityAdapterConfig(adapter.input_dim, adapter.intermediate_dim,
                                                                   adapter.output_dim, adapter.dropout_rate),
@@ -623,7 +644,23 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
                     llama_decoder=LlamaDecoder(llama_config_from_spec(llama), dtype, device))
         if seed is not None:
             model.fill_synthetic(seed)
-        return model
+        return model.set_gemm_dtype(gemm_dtype)
+
+    def set_gemm_dtype(self, gemm_dtype: str = "model"):
+        """"fp8": the eight projections of both frozen towers run on the fp8 MFMA kernel -- weights quantised once to e4m3
+        with one power-of-two (E8M0) scale per output channel, activations per token on the fly (BASELINE.json configs[4];
+        DESIGN.md section 9).  "model": GEMMs in the model dtype.  The HF-named parameters stay the masters either way
+        (checkpoints are unaffected); the adapter, the only trained block, always stays in the model dtype."""
+        if gemm_dtype not in ("model", "fp8"):
+            raise ValueError("gemm_dtype must be 'model' or 'fp8'")
+        on = gemm_dtype == "fp8"
+        if on and self.esm_encoder.dtype != torch.bfloat16:
+            raise ValueError("fp8 GEMMs need a bf16 model")
+        for tower in (self.esm_encoder, self.llama_decoder.model):
+            if tower.gemm_fp8 != on:
+                tower.gemm_fp8 = on
+                tower.invalidate_engine()
+        return self
 
     def fill_synthetic(self, seed: int = 0):
         """Weights from the counter-hash generator (p2t_hip.synth), identical to what the oracle and

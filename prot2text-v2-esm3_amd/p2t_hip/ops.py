@@ -111,6 +111,52 @@ def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, i
     return q, kk, v
 
 
+def quant_rows_fp8(x: torch.Tensor, cols: int | None = None, ld_q: int | None = None):
+    """Row-wise e4m3 quantisation with one E8M0 (power-of-two) scale byte per row -> (q uint8 [rows, ld_q], scale uint8 [rows])."""
+    _chk(x.dim() == 2 and x.stride(1) == 1, "quant_rows_fp8: 2-D row-major input")
+    rows = x.shape[0]
+    cols = x.shape[1] if cols is None else cols
+    ld_q = round_up(cols, 128) if ld_q is None else ld_q
+    q = torch.empty((rows, ld_q), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.uint8, device=x.device)
+    call("p2t_quant_rows_fp8", ptr(x), dt_of(x), x.stride(0), rows, cols, ptr(q), ld_q, ptr(sc), stream())
+    return q, sc
+
+
+def norm_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, eps: float, ld_q: int | None = None):
+    """LayerNorm (b given) or RMSNorm (b None) of the f32 stream, written as e4m3 + E8M0 row scales."""
+    _chk(x.dtype == torch.float32 and x.dim() == 2, "norm_fp8: x must be f32 [rows, cols]")
+    rows, cols = x.shape
+    ld_q = round_up(cols, 128) if ld_q is None else ld_q
+    q = torch.empty((rows, ld_q), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.uint8, device=x.device)
+    if b is not None:
+        call("p2t_layernorm_fp8", ptr(x), x.stride(0), ptr(w), ptr(b), float(eps), ptr(q), ld_q, ptr(sc), rows, cols, stream())
+    else:
+        call("p2t_rmsnorm_fp8", ptr(x), x.stride(0), ptr(w), float(eps), ptr(q), ld_q, ptr(sc), rows, cols, stream())
+    return q, sc
+
+
+def gemm_nt_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: torch.Tensor | None = None, *,
+                n: int | None = None, k: int | None = None, epilogue: int = _lib.EPI_STORE, out: torch.Tensor | None = None,
+                out_dtype: torch.dtype = torch.bfloat16, z: torch.Tensor | None = None, tile: int = 0) -> torch.Tensor:
+    """epilogue((a8 * 2^(a_scale-127)) @ (w8 * 2^(w_scale-127)).T) on the fp8 MFMA kernel; a8 [M, lda], w8 [>= n, ldw] uint8."""
+    _chk(a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.dim() == 2 and w8.dim() == 2, "gemm_nt_fp8: uint8 (e4m3) operands")
+    _chk(a_scale.dtype == torch.uint8 and w_scale.dtype == torch.uint8, "gemm_nt_fp8: uint8 (E8M0) row scales")
+    M = a8.shape[0]
+    n = w8.shape[0] if n is None else n
+    k = min(a8.shape[1], w8.shape[1]) if k is None else k
+    _chk(a_scale.numel() >= M and w_scale.numel() >= n, "gemm_nt_fp8: one scale per row")
+    n_out = n // 2 if epilogue == _lib.EPI_SWIGLU else n
+    if out is None:
+        od = torch.float32 if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else out_dtype
+        ldc = n_out if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else round_up(n_out, 64)
+        out = torch.empty((M, ldc), dtype=od, device=a8.device)
+    call("p2t_gemm_nt_fp8", ptr(a8), a8.stride(0), ptr(a_scale), ptr(w8), w8.stride(0), ptr(w_scale), ptr(bias), ptr(out), out.stride(0),
+         ptr(z), M, n, k, dt_of(out), epilogue, 0, int(tile), stream())
+    return out
+
+
 def positions_where(values: torch.Tensor, match: int | None = None):
     """Flat positions (int32, array order) of `values == match` (or `values != 0` when match is None) and their count
     (int32 [1]), both on the device: the enumeration order of torch's boolean-mask indexing."""

@@ -101,6 +101,8 @@ CONFIGS = {
     "cfg2": ("esm2_t12_35M", "Llama-3.2-1B", "bf16", 32, 512, 128),
     "cfg3": ("esm2_t36_3B", "Llama-3.1-8B-Instruct", "bf16", 16, 1024, 128),
     "cfg4": ("esm2_t36_3B", "Llama-3.1-8B-Instruct", "bf16", 32, 1024, 128),
+    # configs[4]: fp8-e4m3 tower weights + GEMM operands (fp8 MFMA), bf16 activations; global batch 512 over 8 GPUs
+    "cfg5": ("esm2_t36_3B", "Llama-3.1-8B-Instruct", "fp8", 64, 1024, 128),
 }
 
 
