@@ -212,6 +212,9 @@ typedef struct {
     const float* ln1_w;                              /* input_layernorm */
     const float* ln2_w;                              /* post_attention_layernorm */
     const uint8_t* qkv_ws; const uint8_t* o_ws; const uint8_t* gu_ws; const uint8_t* down_ws;   /* gemm_fp8: E8M0 row scales */
+    /* Qwen3 (both or neither): self_attn.q_norm / k_norm weights, f32 [head_dim] -- RMSNorm over head_dim of every query /
+     * key head after the projection and before the rotation (HF Qwen3Attention.forward).  qkv_w rows are then in natural order. */
+    const float* q_norm_w; const float* k_norm_w;
 } p2t_llama_layer;
 
 typedef struct {

@@ -329,6 +329,12 @@ def llama_layer(spec, W, i, x, bias, cos, sin, prec: Precision = FP32, prefix=""
     q = (h @ wq("self_attn.q_proj").T).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
     k = (h @ wq("self_attn.k_proj").T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
     v = (h @ wq("self_attn.v_proj").T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+    if getattr(spec, "qk_norm", False):
+        # Qwen3 (transformers/models/qwen3/modeling_qwen3.py, Qwen3Attention.forward): q_norm / k_norm = RMSNorm over
+        # head_dim of every head after the projection (stored in the model dtype here), before the rotation
+        q = rms_norm(q_(q), W[p + "self_attn.q_norm.weight"], spec.rms_norm_eps)
+        k = rms_norm(q_(k), W[p + "self_attn.k_norm.weight"], spec.rms_norm_eps)
+        v = q_(v)
     q = q * cos + rotate_half(q) * sin
     k = k * cos + rotate_half(k) * sin
     q, k, v = q_(q), q_(k), q_(v)

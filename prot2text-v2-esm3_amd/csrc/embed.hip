@@ -173,6 +173,58 @@ __global__ void __launch_bounds__(256) qkv_post_kernel(const T* __restrict__ qkv
     }
 }
 
+// Qwen3: head split with RMSNorm over head_dim on every query / key head (f32 statistics, eps inside the root, weight last:
+// HF Qwen3RMSNorm = LlamaRMSNorm) followed by the rotation; value heads are copied.  One wave per (token, head): lane j < d/2
+// holds the rotary pair (j, j + d/2).  Restates HF Qwen3Attention.forward up to the attention call.
+template <typename T>
+__global__ void __launch_bounds__(256) qk_norm_rope_kernel(const T* __restrict__ qkv, int64_t ldq, const float* __restrict__ cs,
+                                                           const float* __restrict__ qw, const float* __restrict__ kw, float eps,
+                                                           T* __restrict__ q, T* __restrict__ k, T* __restrict__ v, int64_t rows, int seq,
+                                                           int nh, int nkv, int d, int dp) {
+    const int lane = threadIdx.x & 63, heads = nh + 2 * nkv, half = d / 2;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t bt = row / heads;
+    const int hh = (int)(row - bt * heads);
+    const int b = (int)(bt / seq), t = (int)(bt - (int64_t)b * seq);
+    const T* src = qkv + bt * ldq + (int64_t)hh * d;
+    float x1 = 0.f, x2 = 0.f;
+    if (lane < half) { x1 = to_f32(src[lane]); x2 = to_f32(src[lane + half]); }
+    T* dst;
+    if (hh < nh + nkv) {
+        const bool is_q = hh < nh;
+        const float* w = is_q ? qw : kw;
+        const float ss = wave_sum(x1 * x1 + x2 * x2);
+        const float rstd = rsqrtf(ss / (float)d + eps);
+        dst = is_q ? q + (((int64_t)b * nh + hh) * seq + t) * dp : k + (((int64_t)b * nkv + (hh - nh)) * seq + t) * dp;
+        if (lane < half) {
+            const float a1 = w[lane] * (x1 * rstd), a2 = w[lane + half] * (x2 * rstd);
+            const float c = cs[(int64_t)t * d + lane], s = cs[(int64_t)t * d + half + lane];
+            dst[lane] = from_f32<T>(a1 * c - a2 * s);
+            dst[lane + half] = from_f32<T>(a2 * c + a1 * s);
+        }
+    } else {
+        dst = v + (((int64_t)b * nkv + (hh - nh - nkv)) * seq + t) * dp;
+        if (lane < half) { dst[lane] = from_f32<T>(x1); dst[lane + half] = from_f32<T>(x2); }
+    }
+    for (int c = d + lane; c < dp; c += 64) dst[c] = from_f32<T>(0.f);
+}
+
+int launch_qk_norm_rope(const void* qkv, int64_t ldq, const float* cs, const float* q_norm_w, const float* k_norm_w, float eps, void* q,
+                        void* k, void* v, int B, int T, int nh, int nkv, int d, int dp, int dtype, hipStream_t s) {
+    P2T_REQUIRE(d % 2 == 0 && d <= 128 && dp >= d && dp <= 128 && q_norm_w && k_norm_w, "qk_norm_rope: head_dim %d (padded %d) unsupported", d, dp);
+    const int64_t rows = (int64_t)B * T * (nh + 2 * nkv);
+    const dim3 grid((unsigned)ceil_div(rows, 4));
+    if (dtype == P2T_BF16)
+        qk_norm_rope_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)qkv, ldq, cs, q_norm_w, k_norm_w, eps, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v,
+                                                          rows, T, nh, nkv, d, dp);
+    else
+        qk_norm_rope_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, ldq, cs, q_norm_w, k_norm_w, eps, (float*)q, (float*)k, (float*)v, rows,
+                                                         T, nh, nkv, d, dp);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
 int launch_mask_prepare(const int64_t* ids, const int64_t* mask, int B, int T, int mask_id, int token_dropout,
                         uint8_t* key_mask, int32_t* kv_info, float* emb_scale, hipStream_t s) {
     mask_prepare_kernel<<<B, 256, 0, s>>>(ids, mask, T, mask_id, token_dropout, key_mask, kv_info, emb_scale);

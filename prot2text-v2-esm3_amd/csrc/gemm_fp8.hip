@@ -35,7 +35,17 @@ __device__ __forceinline__ f32x4 mfma_fp8(const v8i& a, const v8i& b, const f32x
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, sa, OB, sb);
 }
 
-template <int MT, typename Epi>
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+// the same skeleton on bf16 operands (experiment, p2t_set_gemm_policy(6)): a K step of 128 BYTES is 64 bf16 elements, the two
+// 64-byte halves of a fragment feed two v_mfma_f32_16x16x32_bf16
+__device__ __forceinline__ f32x4 mfma_bf16_pair(const v8i& a, const v8i& b, f32x4 c) {
+    const v4i alo = __builtin_shufflevector(a, a, 0, 1, 2, 3), ahi = __builtin_shufflevector(a, a, 4, 5, 6, 7);
+    const v4i blo = __builtin_shufflevector(b, b, 0, 1, 2, 3), bhi = __builtin_shufflevector(b, b, 4, 5, 6, 7);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, alo), __builtin_bit_cast(bf16x8v, blo), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, ahi), __builtin_bit_cast(bf16x8v, bhi), c, 0, 0, 0);
+}
+
+template <int MT, typename Epi, bool F8 = true>
 __global__ void __launch_bounds__(512)
     gemm_nt_fp8_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ a_scale, const uint8_t* __restrict__ W,
                        int64_t ldw, const uint8_t* __restrict__ w_scale, int64_t M, int N, int K, int tiles_m, int tiles_n, int n_cover,
@@ -107,16 +117,16 @@ __global__ void __launch_bounds__(512)
     // ---- prologue: DMA of K steps 0 and 1, then the row scales (E8M0 bytes, one per operand row, packed per fragment) ----
     issue_all(0);
     if (ns > 1) issue_all(1);
-    int sx[MT / 4 > 0 ? MT / 4 : 1], sw8 = 0;
+    int sx[MT / 4 > 0 ? MT / 4 : 1] = {0}, sw8 = 0;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
+    for (int j = 0; F8 && j < MT; ++j) {
         int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
         m = m < M ? m : M - 1;
         const int e = a_scale[m];
         if ((j & 3) == 0) sx[j >> 2] = e; else sx[j >> 2] |= e << (8 * (j & 3));
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
+    for (int i = 0; F8 && i < NT; ++i) {
         const int r = i * 16 + fr;
         const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
         int n = n0 + wn * 64 + nl;
@@ -150,8 +160,13 @@ __global__ void __launch_bounds__(512)
             constexpr int I = decltype(ii)::value;
             auto two = [&](auto jj) {                       // MFMAs (I, J), (I, J + 1)
                 constexpr int J = decltype(jj)::value;
-                acc[I][J] = mfma_fp8<I, J & 3>(Wf[I], X[J], acc[I][J], sw8, sx[J >> 2]);
-                acc[I][J + 1] = mfma_fp8<I, (J + 1) & 3>(Wf[I], X[J + 1], acc[I][J + 1], sw8, sx[(J + 1) >> 2]);
+                if constexpr (F8) {
+                    acc[I][J] = mfma_fp8<I, J & 3>(Wf[I], X[J], acc[I][J], sw8, sx[J >> 2]);
+                    acc[I][J + 1] = mfma_fp8<I, (J + 1) & 3>(Wf[I], X[J + 1], acc[I][J + 1], sw8, sx[(J + 1) >> 2]);
+                } else {
+                    acc[I][J] = mfma_bf16_pair(Wf[I], X[J], acc[I][J]);
+                    acc[I][J + 1] = mfma_bf16_pair(Wf[I], X[J + 1], acc[I][J + 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             auto dma2 = [&](auto pp) {                      // DMA piece pp of step s + 2
@@ -165,18 +180,24 @@ __global__ void __launch_bounds__(512)
                     X[J + 1] = frag(s + 1, x_off + (J + 1) * 1024);
                 }
             };
+            // DMA of step s + 2 as EARLY in the step as the issue slots allow (rows 0 and 1, one piece per MFMA pair): its data
+            // is waited for at the top of step s + 1, so every cycle it is issued earlier is latency hidden
+            constexpr int PPR = MT >= 8 ? 4 : 2;            // pieces per row
             two(std::integral_constant<int, 0>{});
-            dma2(std::integral_constant<int, 2 * I>{});
+            dma2(std::integral_constant<int, (I < 2 ? PPR * I : NP)>{});
             reloadx(std::integral_constant<int, 0>{});
             two(std::integral_constant<int, 2>{});
-            dma2(std::integral_constant<int, 2 * I + 1>{});
+            dma2(std::integral_constant<int, (I < 2 ? PPR * I + 1 : NP)>{});
             reloadx(std::integral_constant<int, 2>{});
             if constexpr (MT >= 8) {
                 two(std::integral_constant<int, 4>{});
+                dma2(std::integral_constant<int, (I < 2 ? PPR * I + 2 : NP)>{});
                 reloadx(std::integral_constant<int, 4>{});
                 two(std::integral_constant<int, 6>{});
+                dma2(std::integral_constant<int, (I < 2 ? PPR * I + 3 : NP)>{});
                 reloadx(std::integral_constant<int, 6>{});
             }
+            if constexpr (MT < 8 && I < 2) dma2(std::integral_constant<int, 4 + I>{});   // 128-row tiles: 6 pieces, 3 per row
             if constexpr (MORE) Wf[I] = frag(s + 1, w_off + I * 1024);   // row I done: its W fragment is free
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -234,6 +255,28 @@ int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const vo
 #undef P2T_FP8_CASE
     set_error("gemm (fp8): unsupported epilogue %d", epilogue);
     return P2T_ERR_ARG;
+}
+
+// experiment: bf16 operands through the 64-deep single-barrier skeleton (policy 6).  K in elements, strides in elements.
+template <typename Epi>
+static int launch_k64(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, const EpiParams& ep,
+                      hipStream_t s) {
+    const int tiles_m = (int)ceil_div(M, 256), tiles_n = (int)ceil_div(n_cover, 256);
+    gemm_nt_fp8_kernel<8, Epi, false><<<dim3((unsigned)(tiles_m * tiles_n)), 512, 0, s>>>((const uint8_t*)A, lda * 2, nullptr, (const uint8_t*)W, ldw * 2,
+                                                                                         nullptr, M, N, K * 2, tiles_m, tiles_n, n_cover, ep);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+int launch_gemm_bf16_k64(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int out_dtype,
+                         int epilogue, const EpiParams& ep, hipStream_t s) {
+    if (K % 64) return P2T_ERR_UNSUPPORTED;
+    const bool ob = out_dtype == P2T_BF16;
+    switch (epilogue) {
+        case P2T_EPI_STORE: return ob ? launch_k64<EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s) : launch_k64<EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_GELU: return ob ? launch_k64<EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s) : launch_k64<EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_RESID: return launch_k64<EpiResid>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+    }
+    return P2T_ERR_UNSUPPORTED;
 }
 
 }  // namespace p2t

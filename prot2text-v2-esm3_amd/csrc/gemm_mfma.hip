@@ -522,7 +522,14 @@ size_t gemm_fix_header_bytes() { return kFixHeader; }
 template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                         const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes, unsigned fix_epoch, hipStream_t s) {
-    if (tile == 0) tile = g_gemm_policy.load(std::memory_order_relaxed);   // 128 | 256: tile height; 1: no split-K tail; 2: no persistent kernel; 3 / 4 / 5 below
+    if (tile == 0) tile = g_gemm_policy.load(std::memory_order_relaxed);
+    if (tile == 6) {                                        // experiment: 64-deep single-barrier skeleton of gemm_fp8.hip
+        extern int launch_gemm_bf16_k64(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, hipStream_t);
+        const int rc = launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, n_cover, std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiStore<float>>::value || std::is_same<Epi, EpiGelu<float>>::value ? P2T_F32 : P2T_BF16,
+                                            std::is_same<Epi, EpiResid>::value ? P2T_EPI_RESID : (std::is_same<Epi, EpiGelu<bf16_t>>::value || std::is_same<Epi, EpiGelu<float>>::value ? P2T_EPI_GELU : (std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value ? P2T_EPI_STORE : -1)), ep, s);
+        if (rc != P2T_ERR_UNSUPPORTED) return rc;
+        tile = 0;
+    }   // 128 | 256: tile height; 1: no split-K tail; 2: no persistent kernel; 3 / 4 / 5 below
     const int kCUs = cu_count();
     {
         // persistent kernel: shapes without edge tiles and at least one whole round of tiles.  tile: 0 / 3 = with the

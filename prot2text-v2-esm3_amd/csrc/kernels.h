@@ -28,6 +28,9 @@ int launch_rope_table(const float* inv_freq, int T, int half, float* cs, hipStre
 int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void* k, void* v, int B, int T, int nh, int nkv,
                     int d, int dp, float q_scale, int dtype, hipStream_t s);
 
+int launch_qk_norm_rope(const void* qkv, int64_t ldq, const float* cs, const float* q_norm_w, const float* k_norm_w, float eps, void* q,
+                        void* k, void* v, int B, int T, int nh, int nkv, int d, int dp, int dtype, hipStream_t s);
+
 int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int dtype,
                        int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s);
 int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,

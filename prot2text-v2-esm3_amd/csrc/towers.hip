@@ -209,7 +209,8 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
                               size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(c && w && (ids || inputs_embeds) && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
     P2T_REQUIRE(k >= 0 && k <= c->n_layers, "p2t_llama_hidden_forward: hidden_states[%d] out of range for %d layers", k, c->n_layers);
-    P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 32 == 0,
+    P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 32 == 0 &&
+                    ((int64_t)c->heads * c->head_dim) % 16 == 0,
                 "p2t_llama_hidden_forward: unsupported shape");
     P2T_REQUIRE((w->embed || !ids) && (k == 0 || w->layers) && (k < c->n_layers || w->final_norm_w), "p2t_llama_hidden_forward: missing weights");
     P2T_REQUIRE(workspace_bytes >= p2t_llama_workspace_bytes(c, B, T), "p2t_llama_hidden_forward: workspace too small");
@@ -251,8 +252,14 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
             g.a_scale = as; g.w_scale = ws;
             return g;
         };
+        P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_hidden_forward: q_norm_w and k_norm_w go together (layer %d)", l);
         P2T_TRY(launch_rmsnorm_fp8(b.x, H, L.ln1_w, c->rms_norm_eps, b.hq, Hq, b.hs, M, H, s));
-        if (d == 64 || d == 128) {
+        if (L.q_norm_w) {          // Qwen3: projection -> per-head RMSNorm -> rotation (not fusable: the norm spans the head)
+            GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, b.qkv, NQKV, NQKV, Hq, dt, P2T_EPI_STORE);
+            g1.n_zero = (int)NQKV;
+            P2T_TRY(gemm_nt(g1, s));
+            P2T_TRY(launch_qk_norm_rope(b.qkv, NQKV, b.cs, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, b.q, b.k, b.v, B, T, nh, nkv, d, dp, dt, s));
+        } else if (d == 64 || d == 128) {
             GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, nullptr, 0, NQKV, Hq, dt, P2T_EPI_QKV_ROPE);
             g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f; g1.head_dim = d;
             P2T_TRY(gemm_nt(g1, s));
@@ -275,8 +282,13 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
     }
     for (int l = 0; !c->gemm_fp8 && l < k; ++l) {
         const p2t_llama_layer& L = w->layers[l];
+        P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_hidden_forward: q_norm_w and k_norm_w go together (layer %d)", l);
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
-        if (d == 64 || d == 128) {
+        if (L.q_norm_w) {          // Qwen3: projection -> per-head RMSNorm -> rotation (not fusable: the norm spans the head)
+            GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
+            P2T_TRY(gemm_nt(g1, s));
+            P2T_TRY(launch_qk_norm_rope(b.qkv, NQKV, b.cs, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, b.q, b.k, b.v, B, T, nh, nkv, d, dp, dt, s));
+        } else if (d == 64 || d == 128) {
             // bias-free QKV projection + rotary + head split in the GEMM epilogue (d = 128: rows packed per head, see the header)
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, nullptr, 0, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_QKV_ROPE, 0, -1, -1, 0.f, 0, 0};
             g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f; g1.head_dim = d;

@@ -55,7 +55,8 @@ class LlamaConfigC(C.Structure):
 
 
 class LlamaLayerC(C.Structure):
-    _fields_ = [(n, vp) for n in ("qkv_w", "o_w", "gu_w", "down_w", "ln1_w", "ln2_w", "qkv_ws", "o_ws", "gu_ws", "down_ws")]
+    _fields_ = [(n, vp) for n in ("qkv_w", "o_w", "gu_w", "down_w", "ln1_w", "ln2_w", "qkv_ws", "o_ws", "gu_ws", "down_ws",
+                                  "q_norm_w", "k_norm_w")]
 
 
 class LlamaWeightsC(C.Structure):

@@ -43,7 +43,11 @@ class Esm2LlamaInstructConfig(PretrainedConfig):
         if isinstance(adapter_config, dict):
             adapter_config = ModalityAdapterConfig(**{k: v for k, v in adapter_config.items() if k != "model_type"})
         if isinstance(llama_config, dict):
-            llama_config = LlamaConfig(**{k: v for k, v in llama_config.items() if k != "model_type"})
+            if llama_config.get("model_type") == "qwen3":
+                from transformers import Qwen3Config
+                llama_config = Qwen3Config(**{k: v for k, v in llama_config.items() if k != "model_type"})
+            else:
+                llama_config = LlamaConfig(**{k: v for k, v in llama_config.items() if k != "model_type"})
         self.esm_config = esm_config
         self.adapter_config = adapter_config
         self.llama_config = llama_config
@@ -89,7 +93,13 @@ def _rope_dict(c: LlamaConfig) -> dict:
 
 
 def llama_spec_from_config(c: LlamaConfig) -> specs.LlamaSpec:
+    """LlamaConfig, or Qwen3Config (model_type "qwen3": the same block plus q_norm / k_norm, models/esmc_qwen_arc.py's LLM)."""
     rp = _rope_dict(c)
+    mt = getattr(c, "model_type", "llama")
+    if mt not in ("llama", "qwen3"):
+        raise ValueError(f"decoder model_type={mt!r} is not supported (llama, qwen3)")
+    if mt == "qwen3" and (getattr(c, "use_sliding_window", False) or any(t != "full_attention" for t in (getattr(c, "layer_types", None) or []))):
+        raise ValueError("Qwen3 sliding-window layers are not supported")
     if rp["rope_type"] not in ("default", "llama3"):
         raise ValueError(f"Llama rope_type={rp['rope_type']!r} is not supported (default, llama3)")
     if getattr(c, "attention_bias", False) or getattr(c, "mlp_bias", False):
@@ -104,11 +114,20 @@ def llama_spec_from_config(c: LlamaConfig) -> specs.LlamaSpec:
                            rope_original_max_position_embeddings=int(rp.get("original_max_position_embeddings", 8192)),
                            max_position_embeddings=c.max_position_embeddings,
                            tie_word_embeddings=bool(getattr(c, "tie_word_embeddings", False)),
-                           head_dim=getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads)
+                           head_dim=getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads,
+                           qk_norm=mt == "qwen3")
 
 
 def llama_config_from_spec(s: specs.LlamaSpec) -> LlamaConfig:
     rope = {"rope_type": s.rope_type, "rope_theta": s.rope_theta}
+    if s.qk_norm:
+        from transformers import Qwen3Config
+        return Qwen3Config(vocab_size=s.vocab_size, hidden_size=s.hidden_size, intermediate_size=s.intermediate_size,
+                           num_hidden_layers=s.num_hidden_layers, num_attention_heads=s.num_attention_heads,
+                           num_key_value_heads=s.num_key_value_heads, head_dim=s.head_dim, rms_norm_eps=s.rms_norm_eps,
+                           max_position_embeddings=s.max_position_embeddings, rope_parameters=rope,
+                           tie_word_embeddings=s.tie_word_embeddings, attention_bias=False, attention_dropout=0.0,
+                           use_sliding_window=False, pad_token_id=None, bos_token_id=None, eos_token_id=None)
     if s.rope_type == "llama3":
         rope.update(factor=s.rope_factor, low_freq_factor=s.rope_low_freq_factor,
                     high_freq_factor=s.rope_high_freq_factor,

@@ -414,13 +414,15 @@ class LlamaTextModel(nn.Module):
         for i in range(n_layers):
             p = f"layers.{i}."
             qkv = torch.cat([P[p + f"self_attn.{n}_proj.weight"].detach() for n in ("q", "k", "v")], 0)
-            if d == 128:        # per head: rows 0..31, 64..95, 32..63, 96..127 (include/p2t_hip.h, p2t_llama_layer)
+            if d == 128 and not s.qk_norm:   # per head: rows 0..31, 64..95, 32..63, 96..127 (include/p2t_hip.h, p2t_llama_layer)
                 qkv = qkv.view(-1, 2, 2, 32, H).transpose(1, 2).reshape(-1, H)
             gate, up = P[p + "mlp.gate_proj.weight"].detach(), P[p + "mlp.up_proj.weight"].detach()
             gu = torch.stack([gate.view(F // 32, 32, H), up.view(F // 32, 32, H)], 1).reshape(2 * F, H)   # 32-row gate/up blocks
             t = dict(qkv_w=_pad_cols(qkv, Hp, dt), o_w=_pad_cols(P[p + "self_attn.o_proj.weight"], QO, dt),
                      gu_w=_pad_cols(gu, Hp, dt), down_w=_pad_cols(P[p + "mlp.down_proj.weight"], Fp, dt),
                      ln1_w=_f32(P[p + "input_layernorm.weight"]), ln2_w=_f32(P[p + "post_attention_layernorm.weight"]))
+            if s.qk_norm:               # Qwen3: natural row order, the per-head norm runs between projection and rotation
+                t["q_norm_w"], t["k_norm_w"] = _f32(P[p + "self_attn.q_norm.weight"]), _f32(P[p + "self_attn.k_norm.weight"])
             if self.gemm_fp8:
                 for name, kdim in (("qkv", H), ("o", s.num_attention_heads * d), ("gu", H), ("down", F)):
                     t[name + "_w"], t[name + "_ws"] = _quant_fp8(t[name + "_w"], kdim)

@@ -53,6 +53,7 @@ class LlamaSpec:
     max_position_embeddings: int = 131072
     tie_word_embeddings: bool = False
     head_dim: int = 0
+    qk_norm: bool = False               # Qwen3: RMSNorm over head_dim on every query / key head before the rotation
 
     def __post_init__(self):
         if not self.head_dim:
@@ -80,6 +81,17 @@ LLAMA = {
     "Llama-3.1-8B-Instruct": dict(num_hidden_layers=32, hidden_size=4096, intermediate_size=14336,
                                   num_attention_heads=32, num_key_value_heads=8, rope_factor=8.0),
 }
+
+
+# Qwen3 = the Llama block + per-head q / k RMSNorm, explicit head_dim 128, no llama3 rope scaling (the text tower the
+# fork's scripts instantiate: models/esmc_config.py:9 "Qwen/Qwen3-14B"; public HF config values, restated not fetched)
+LLAMA["Qwen3-14B"] = dict(num_hidden_layers=40, hidden_size=5120, intermediate_size=17408, num_attention_heads=40,
+                          num_key_value_heads=8, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
+                          rope_type="default", rope_factor=1.0, max_position_embeddings=40960, qk_norm=True)
+LLAMA["Qwen3-0.6B"] = dict(num_hidden_layers=28, hidden_size=1024, intermediate_size=3072, num_attention_heads=16,
+                           num_key_value_heads=8, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=1e6,
+                           rope_type="default", rope_factor=1.0, max_position_embeddings=40960, qk_norm=True,
+                           tie_word_embeddings=True)
 
 
 def esm_spec(name: str, **over) -> EsmSpec:
@@ -146,6 +158,9 @@ def llama_tensors(s: LlamaSpec, prefix: str = "", layers: int | None = None,
         yield p + "self_attn.k_proj.weight", (nkv, H), _lin(H), 0.0
         yield p + "self_attn.v_proj.weight", (nkv, H), _lin(H), 0.0
         yield p + "self_attn.o_proj.weight", (H, nq), _lin(nq), 0.0
+        if s.qk_norm:
+            yield p + "self_attn.q_norm.weight", (d,), 0.2, 1.0
+            yield p + "self_attn.k_norm.weight", (d,), 0.2, 1.0
         yield p + "mlp.gate_proj.weight", (F, H), _lin(H), 0.0
         yield p + "mlp.up_proj.weight", (F, H), _lin(H), 0.0
         yield p + "mlp.down_proj.weight", (H, F), _lin(F), 0.0

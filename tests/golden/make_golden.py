@@ -94,9 +94,20 @@ def build_reference_model(ref, esm: specs.EsmSpec, llama: specs.LlamaSpec, ad: s
                        tie_word_embeddings=llama.tie_word_embeddings, attention_bias=False, mlp_bias=False,
                        attention_dropout=0.0, pad_token_id=None, bos_token_id=None, eos_token_id=None)
     lcfg._attn_implementation = "eager"
+    if llama.qk_norm:
+        # the text tower the fork's scripts instantiate is a Qwen3 (models/esmc_config.py:9): random-init HF Qwen3ForCausalLM
+        # from a local config -- same decoder interface (`.model(..., output_hidden_states=True)`) as the Llama one
+        from transformers import Qwen3Config, Qwen3ForCausalLM
+        lcfg = Qwen3Config(vocab_size=llama.vocab_size, hidden_size=llama.hidden_size, intermediate_size=llama.intermediate_size,
+                           num_hidden_layers=llama.num_hidden_layers, num_attention_heads=llama.num_attention_heads,
+                           num_key_value_heads=llama.num_key_value_heads, head_dim=llama.head_dim, rms_norm_eps=llama.rms_norm_eps,
+                           max_position_embeddings=llama.max_position_embeddings, rope_parameters=rope,
+                           tie_word_embeddings=llama.tie_word_embeddings, attention_bias=False, attention_dropout=0.0,
+                           use_sliding_window=False, pad_token_id=None, bos_token_id=None, eos_token_id=None)
+        lcfg._attn_implementation = "eager"
     with torch.device("cpu"):
         esm_m = EsmModel(ecfg, add_pooling_layer=False)
-        llama_m = LlamaForCausalLM(lcfg)
+        llama_m = Qwen3ForCausalLM(lcfg) if llama.qk_norm else LlamaForCausalLM(lcfg)
         acfg = ref.mc.ModalityAdapterConfig(input_dim=ad.input_dim, intermediate_dim=ad.intermediate_dim,
                                             output_dim=ad.output_dim, dropout_rate=ad.dropout_rate)
         adapter = ref.mm.ModalityAdapter(acfg)
@@ -417,7 +428,7 @@ def run_sft(ref):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,cfg1,collate,train_state,sft")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -463,6 +474,17 @@ def main():
         ad = specs.AdapterSpec(128, 96, 128, 0.3)
         run_case(ref, "tiny_d64", esm, llama, ad, B=5, T_p=70, T_t=24, p_lens=[70, 64, 33, 9, 3], t_lens=[24, 17, 8, 2, 1],
                  layers=[1, 2], id_high=290, pad_id=299, eos_id=298)
+    if "tiny_qwen3" in only:
+        # SURVEY.md section 8f row 4, the half that can be pinned offline: a Qwen3 text tower (per-head q / k RMSNorm, head_dim 128
+        # that is NOT hidden / heads, GQA 2:1, default rope with theta 1e6) driven through the reference's own
+        # get_description_embeddings; the protein side stays the ESM2 encoder (ESM-C needs the absent `esm` package)
+        esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+        llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=192, intermediate_size=320, num_attention_heads=4,
+                                num_key_value_heads=2, vocab_size=300, head_dim=128, rms_norm_eps=1e-6, rope_theta=1e6,
+                                rope_type="default", rope_factor=1.0, qk_norm=True)
+        ad = specs.AdapterSpec(64, 80, 192, 0.3)
+        run_case(ref, "tiny_qwen3", esm, llama, ad, B=4, T_p=24, T_t=40, p_lens=[24, 15, 7, 3], t_lens=[40, 33, 9, 2],
+                 layers=[2, 3], id_high=290, pad_id=299, eos_id=298)
     if "cfg1" in only:
         name_e, name_l, _, B, T_p, T_t = specs.CONFIGS["cfg1"]
         esm, llama = specs.esm_spec(name_e), specs.llama_spec(name_l)

@@ -25,7 +25,7 @@ def _batch(pid, pmask, tid, tmask):
                 description_input_ids=to_dev(tid), description_attention_mask=to_dev(tmask))
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64", "tiny_qwen3"])
 def test_fp32_towers_vs_reference_goldens(golden, case):
     import p2t_hip as P
     g = golden(case)
@@ -61,7 +61,7 @@ def test_fp32_towers_vs_reference_goldens(golden, case):
             assert abs(float(loss) - float(g[f"loss_seg{nseg}_mix_L{k}"])) < LOSS_TOL
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64", "tiny_qwen3"])
 def test_fp32_adapter_gradients_autograd_and_trainer(golden, case):
     """loss.backward() through the autograd wiring, and the fused ContrastiveTrainer, against the
     reference's autograd gradients and its clip + AdamW step."""
@@ -104,7 +104,7 @@ def test_fp32_adapter_gradients_autograd_and_trainer(golden, case):
             np.testing.assert_allclose(to_np(model.adapter.fc2.weight), g["opt_after_fc2.weight"], rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64", "tiny_qwen3"])
 def test_bf16_towers_vs_bf16_oracle_and_goldens(golden, case):
     import p2t_hip as P
     g = golden(case)

@@ -28,7 +28,7 @@ def test_ops_readout_and_losses(golden):
     assert abs(O.infonce_columns(g["p"], g["t"], [1, 4]) - np.mean([O.infonce_columns(g["p"], g["t"], [j]) for j in (1, 4)])) < 1e-6
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64", "tiny_qwen3"])
 def test_towers_and_step(golden, case):
     g = golden(case)
     meta = g["meta"]
@@ -66,7 +66,7 @@ def test_towers_and_step(golden, case):
             assert rel_err(out["grads"]["adapter." + n], g[f"grad_seg{nseg}_{n}"]) < 1e-4, n
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_d24", "tiny_d128", "tiny_d64", "tiny_qwen3"])
 def test_clip_adamw_step(golden, case):
     g = golden(case)
     meta = g["meta"]

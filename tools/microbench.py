@@ -72,7 +72,7 @@ def bench_cold():
         ws, ep = ops.gemm_fix_workspace(dev), [0]
         fl = 2.0 * M * N * K / 1e9
         res = []
-        for env in ("2", "4", "3", "5", None):
+        for env in ("2", "4", "3", "5", None, "6"):
             _lib.call("p2t_set_gemm_policy", int(env or 0))
             tot = 0.0
             for i in range(6):
@@ -89,7 +89,7 @@ def bench_cold():
         _lib.call("p2t_set_gemm_policy", 0)
         print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
               f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | persistent+half-tiles {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f} | "
-              f"default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f}", flush=True)
+              f"default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f} | k64 skeleton {res[5] * 1e3:7.1f} us {fl / res[5]:7.1f}", flush=True)
 
 
 def bench_ksweep():
@@ -158,6 +158,43 @@ def bench_blas():
               f"{res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} TF/s", flush=True)
 
 
+def bench_fp8():
+    """fp8 MFMA GEMM (cfg5) on the tower shapes, operands cold (a 768 MB fill between launches), per tile height; beside it
+    the bf16 kernel's default policy on the same shape, and the cost of the quantise pass that feeds FFN-down / o-proj."""
+    shapes = [("esm qkv", 16384, 7680, 2560, 0), ("esm o", 16384, 2560, 2560, 2), ("esm fc1", 16384, 10240, 2560, 1),
+              ("esm fc2", 16384, 2560, 10240, 2), ("esm qkv b64", 65536, 7680, 2560, 0), ("esm fc2 b64", 65536, 2560, 10240, 2),
+              ("llama qkv", 8192, 6144, 4096, 0), ("llama gu", 8192, 28672, 4096, 3), ("llama down", 8192, 4096, 14336, 2)]
+    flush = torch.empty((768 << 20,), dtype=torch.uint8, device=dev)
+    for name, M, N, K, epi in shapes:
+        a, w = rand((M, K)), rand((N, K), scale=0.05)
+        a8, sa = ops.quant_rows_fp8(a)
+        w8, sw = ops.quant_rows_fp8(w)
+        bias = None if epi == 3 else rand((N,), torch.float32, 0.1)
+        out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
+        fl = 2.0 * M * N * K / 1e9
+        res = []
+        for which in (256, 128, "bf16", "quant"):
+            tot = 0.0
+            for i in range(5):
+                flush.fill_(i)
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                if which == "bf16":
+                    ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1)
+                elif which == "quant":
+                    ops.quant_rows_fp8(a)
+                else:
+                    ops.gemm_nt_fp8(a8, sa, w8, sw, bias, n=N, k=K, epilogue=epi, out=out, tile=which)
+                e0.record()
+                torch.cuda.synchronize()
+                if i > 0:
+                    tot += s0.elapsed_time(e0)
+            res.append(tot / 4)
+        print(f"fp8 {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: 256-row {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | 128-row "
+              f"{res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | bf16 kernel {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | quantise A [{M}x{K}] "
+              f"{res[3] * 1e3:6.1f} us {M * K * 3 / res[3] / 1e6:6.0f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "norm"]
     print(torch.cuda.get_device_name(0), flush=True)
@@ -173,3 +210,5 @@ if __name__ == "__main__":
         bench_norm()
     if "blas" in which:
         bench_blas()
+    if "fp8" in which:
+        bench_fp8()
