@@ -32,15 +32,23 @@ def maxabs(a, b):
 
 
 _OBS_PATH = None
+_TOL_TABLE = None
 
 
 def observe(name, value, tol, what="rel"):
-    """Assert `value < tol` AND append the observed error to gpurun_out/observed_errors.jsonl (merged back from the GPU
-    box), so every bf16 / fp8 tolerance in the suite can be audited against what was actually measured
-    (DESIGN.md section 6 holds the table; tolerances are kept <= 2x the observed value, floor 2^-9 storage rounding)."""
+    """Assert `value < tolerance` AND append the observed error to gpurun_out/observed_errors.jsonl (merged back from the GPU
+    box), so every bf16 / fp8 tolerance in the suite can be audited against what was actually measured.
+    The tolerance enforced is the one in tests/tolerances.json when `name` is listed there (tools/update_tolerances.py writes
+    it from a previous full run: 2 x the largest observed value, never above the inline `tol`), else the inline `tol`."""
     import json
     import os
-    global _OBS_PATH
+    global _OBS_PATH, _TOL_TABLE
+    if _TOL_TABLE is None:
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tolerances.json")
+        _TOL_TABLE = json.load(open(tp)) if os.path.exists(tp) else {}
+    inline_tol = float(tol)
+    if name in _TOL_TABLE:
+        tol = min(inline_tol, float(_TOL_TABLE[name]["tol"]))
     if _OBS_PATH is None:
         root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         d = os.path.join(root, "gpurun_out")
@@ -49,7 +57,7 @@ def observe(name, value, tol, what="rel"):
     value = float(value)
     with open(_OBS_PATH, "a") as f:
         f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "name": name, "kind": what,
-                            "observed": value, "tol": float(tol)}) + "\n")
+                            "observed": value, "tol": float(tol), "inline_tol": inline_tol}) + "\n")
     assert value < tol, f"{name}: observed {what} error {value:.3e} >= tolerance {tol:.3e}"
     return value
 
