@@ -109,7 +109,7 @@ int p2t_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, voi
 /* C[M,N] = (A8 * 2^(a_scale-127))[M,K] * (W8 * 2^(w_scale-127))[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (both scales
  * applied by the instruction), fp32 accumulate, the epilogues of p2t_gemm_nt (all but GELU_BWD).  A8 / W8: e4m3 bytes,
  * row strides lda / ldw in BYTES (multiples of 16), K % 128 == 0 with the padding zeroed; a_scale [M], w_scale [N] E8M0
- * bytes.  tile: 0 auto, 128 / 256 rows. */
+ * bytes.  tile: 0 auto, 128 / 256 = tile height in rows. */
 int p2t_gemm_nt_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
                     const float* bias, void* out, int64_t ldc, void* z, int64_t M, int64_t N, int64_t K, int out_dtype,
                     int epilogue, int accumulate, int tile, p2t_stream stream);

@@ -16,6 +16,10 @@
 //   top of step s:  wait own DMAs (step s+1) + own LDS reads, barrier  ->  DMA of step s+2 into the slots of step s,
 //   interleaved with the 32 MFMAs of step s and the 24 fragment reads of step s+1.
 // Per-tile launch form (one block per tile, XCD-aware grouped tile order), epilogues shared with the bf16 kernel.
+// A persistent form (K loops of consecutive tiles as one stream, undrained epilogue stores, row scales staged through LDS)
+// was built and measured at +6 % .. -2 % of this kernel on the tower shapes (profiles/r02_microbench_fp8_persistent.log): the
+// loop is bound by the global->LDS path (ablation: +26 .. 62 % without the DMA, profiles/r02_microbench_fp8abl.log), not by
+// the tile boundaries, and with 96 fragment registers the tile loop's own state spills -- dropped.
 // Requirements: K % 128 == 0 (producers pad K with zero bytes), lda / ldw % 16 == 0, 16-byte aligned bases.
 #include <type_traits>
 
@@ -45,7 +49,9 @@ __device__ __forceinline__ f32x4 mfma_bf16_pair(const v8i& a, const v8i& b, f32x
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, ahi), __builtin_bit_cast(bf16x8v, bhi), c, 0, 0, 0);
 }
 
-template <int MT, typename Epi, bool F8 = true>
+// ABL (lab only, results are garbage): 1 = no DMA in the K loop, 2 = no fragment reloads, 3 = neither -- what the loop costs
+// without its global->LDS traffic / its LDS reads (tools/microbench.py fp8abl)
+template <int MT, typename Epi, bool F8 = true, int ABL = 0>
 __global__ void __launch_bounds__(512)
     gemm_nt_fp8_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ a_scale, const uint8_t* __restrict__ W,
                        int64_t ldw, const uint8_t* __restrict__ w_scale, int64_t M, int N, int K, int tiles_m, int tiles_n, int n_cover,
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(512)
     // One K step.  MORE: a step s + 1 exists (reload the fragments); ISSUE: a step s + 2 exists (start its DMA).  Both are
     // compile-time so the steady-state body is branch-free; the last two steps are peeled below.
     auto step = [&](auto more_c, auto issue_c, int s) {
-        constexpr bool MORE = decltype(more_c)::value, ISSUE = decltype(issue_c)::value;
+        constexpr bool MORE = decltype(more_c)::value && !(ABL & 2), ISSUE = decltype(issue_c)::value && !(ABL & 1);
         // own fragment reads of step s complete, own DMAs of step s+1 landed; after the barrier: every wave's are, so the
         // slots of step s may be overwritten and the slots of step s+1 may be read
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -236,6 +242,17 @@ static int launch_shape8(const void* A, int64_t lda, const uint8_t* a_scale, con
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, cus);
     const double cost128 = (double)ceil_div(tm128 * tn, cus) * 0.625 * 1.08;
+    if constexpr (std::is_same<Epi, EpiStore<bf16_t>>::value) {
+        if (tile >= 1001 && tile <= 1003) {
+            const int tiles_m = (int)tm256, tiles_n = (int)tn;
+            const dim3 grid((unsigned)(tiles_m * tiles_n));
+            if (tile == 1001) gemm_nt_fp8_kernel<8, Epi, true, 1><<<grid, 512, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, tiles_m, tiles_n, n_cover, ep);
+            if (tile == 1002) gemm_nt_fp8_kernel<8, Epi, true, 2><<<grid, 512, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, tiles_m, tiles_n, n_cover, ep);
+            if (tile == 1003) gemm_nt_fp8_kernel<8, Epi, true, 3><<<grid, 512, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, tiles_m, tiles_n, n_cover, ep);
+            P2T_LAUNCH_CHECK();
+            return P2T_OK;
+        }
+    }
     if (tile == 256 || (tile != 128 && cost256 <= cost128)) return launch_cfg8<8, Epi>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, ep, s);
     return launch_cfg8<4, Epi>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, ep, s);
 }

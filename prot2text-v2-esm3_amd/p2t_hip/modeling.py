@@ -648,6 +648,46 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
             model.fill_synthetic(seed)
         return model.set_gemm_dtype(gemm_dtype)
 
+    # ---- HF-style persistence (the reference class is a PreTrainedModel: models/modeling_esm2llama_instruct.py:71-106) ----
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True):
+        """`config.json` (Esm2LlamaInstructConfig.save_pretrained) + the HF-named state dict (`esm_encoder.*`, `adapter.*`,
+        `llama_decoder.*`) as `model.safetensors` (or `pytorch_model.bin`), as `PreTrainedModel.save_pretrained` lays them out."""
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if self.llama_decoder.spec.tie_word_embeddings:
+            sd.pop("llama_decoder.lm_head.weight", None)             # tied to embed_tokens: stored once, as HF does
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, dtype=None, device="cuda", **kwargs):
+        """Local directory written by `save_pretrained` (of this class or of the reference's): config -> modules -> weights.
+        Weight files are read with loaders that execute nothing (safetensors, or torch.load(weights_only=True))."""
+        import os
+        d = pretrained_model_name_or_path
+        if not os.path.isdir(d):
+            raise ValueError(f"{d!r} is not a local directory (there is no hub access on this path)")
+        config = Esm2LlamaInstructConfig.from_pretrained(d)
+        st = os.path.join(d, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(d, "pytorch_model.bin"), weights_only=True, map_location="cpu")
+        if dtype is None:
+            dtype = next(iter(sd.values())).dtype
+        model = cls(config=config, dtype=dtype, device=device, **kwargs)
+        res = model.load_state_dict(sd, strict=False)
+        bad = [k for k in res.missing_keys if not ("contact_head" in k or "inv_freq" in k or k.endswith("lm_head.weight"))]
+        if bad or res.unexpected_keys:
+            raise RuntimeError(f"checkpoint does not match the configuration: missing {bad}, unexpected {res.unexpected_keys}")
+        return model
+
     def set_gemm_dtype(self, gemm_dtype: str = "model"):
         """"fp8": the eight projections of both frozen towers run on the fp8 MFMA kernel -- weights quantised once to e4m3
         with one power-of-two (E8M0) scale per output channel, activations per token on the fly (BASELINE.json configs[4];

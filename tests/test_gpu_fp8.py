@@ -239,3 +239,37 @@ def test_cfg2_fp8_full_models_vs_fp8_oracle():
     observe("cfg2.fp8_vs_fp32oracle.text", rel(to_np(t), ref32["text"]), 2e-1)
     observe("cfg2.fp8_vs_fp32oracle.protein", rel(to_np(p), ref32["protein"]), 2e-1)
     observe("cfg2.fp8_vs_fp32oracle.loss", abs(loss - float(ref32["loss"])) / max(1.0, abs(float(ref32["loss"]))), 2e-1, "abs/max(1,|ref|)")
+
+
+def test_gemm_fp8_fuzz_vs_exact_kernel(ops):
+    """Random whole-tile shapes (many tiles, 2 .. 11 K steps pairs, per-row scales that differ from row to row) through the
+    fp8 kernel at both tile heights against the exact fp32-FMA kernel on the dequantised operands: a stale ring slot, a
+    mis-counted wait or a wrong scale byte shows up as a wrong tile."""
+    rng = np.random.default_rng(5)
+    for it in range(8):
+        tiles = int(rng.integers(256, 900))
+        tm = int(rng.choice([d for d in range(4, 65) if tiles // d >= 4]))
+        tn = max(4, tiles // tm)
+        M, N, K = 256 * tm, 256 * tn, 128 * int(rng.integers(1, 24))
+        a = torch.empty((M, K), dtype=torch.float32, device=dev())
+        w = torch.empty((N, K), dtype=torch.float32, device=dev())
+        ops.fill_hash_(a, 4, f"pf.a{M}x{K}", 1.0)
+        ops.fill_hash_(w, 4, f"pf.w{N}x{K}", 0.5)
+        a *= torch.exp2(torch.randint(-6, 7, (M, 1), device=dev()).float())
+        w *= torch.exp2(torch.randint(-6, 7, (N, 1), device=dev()).float())
+        a8, sa = ops.quant_rows_fp8(a)
+        w8, sw = ops.quant_rows_fp8(w)
+        da = a8.view(torch.float8_e4m3fn).float() * torch.exp2(sa.float() - 127)[:, None]
+        dw = w8.view(torch.float8_e4m3fn).float() * torch.exp2(sw.float() - 127)[:, None]
+        b = to_dev(rnd(3, "pf.b", (N,), 0.3))
+        for epi in (EPI_STORE, EPI_RESID):
+            ref = ops.gemm_nt(da, dw, b, epilogue=epi, out=torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None,
+                              out_dtype=torch.float32, use_mfma=0)
+            outs = []
+            for tile in (0, 128, 256):
+                got = ops.gemm_nt_fp8(a8, sa, w8, sw, b, n=N, k=K, epilogue=epi, out_dtype=torch.float32, tile=tile,
+                                      out=torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None)
+                err = float((got[:, :N] - ref[:, :N]).abs().max() / ref[:, :N].abs().max())
+                assert err < 1e-4, (M, N, K, epi, tile, err)
+                outs.append(got)
+            assert torch.equal(outs[1][:, :N], outs[2][:, :N])          # both tile heights sum in the same order

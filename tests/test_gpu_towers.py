@@ -306,3 +306,25 @@ def test_dropout_mask_is_consistent_between_forward_and_backward():
     with torch.no_grad():
         other = float(P.teacher_forcing_forward_pass(0, model, b, 1, output_llm_layer=1))
     assert abs(other - float(loss)) > 1e-6
+
+
+def test_save_pretrained_from_pretrained_round_trip(golden, tmp_path):
+    """The PreTrainedModel-style persistence of the assembled model: config.json + model.safetensors with HF key names,
+    reloaded into a fresh model that reproduces the golden outputs."""
+    import p2t_hip as P
+    g = golden("tiny_qwen3")                   # exercises the nested Qwen3 decoder config as well
+    meta = g["meta"]
+    esm, llama, ad, pid, pmask, tid, tmask = case_setup(meta)
+    model = build_model(esm, llama, ad, torch.float32, meta["seed_w"]).eval()
+    model.save_pretrained(str(tmp_path))
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["config.json", "model.safetensors"]
+    again = P.Esm2LlamaInstructForCausalLM.from_pretrained(str(tmp_path)).eval()
+    assert again.llama_decoder.spec.qk_norm and again.config.llama_config.model_type == "qwen3"
+    b = _batch(pid, pmask, tid, tmask)
+    k = meta["layers"][-1]
+    with torch.no_grad():
+        p = P.l2_normalize(P.get_sequence_embeddings(again, b["protein_input_ids"], b["protein_attention_mask"]))
+        t = P.l2_normalize(P.get_description_embeddings(again, b["description_input_ids"], b["description_attention_mask"], k))
+    assert rel(to_np(p), g["prot_norm_mix"]) < F32_TOL and rel(to_np(t), g[f"text_norm_mix_L{k}"]) < F32_TOL
+    with pytest.raises(ValueError):
+        P.Esm2LlamaInstructForCausalLM.from_pretrained("facebook/esm2_t6_8M_UR50D")      # no hub access: local directories only

@@ -195,6 +195,17 @@ def bench_fp8():
               f"{res[3] * 1e3:6.1f} us {M * K * 3 / res[3] / 1e6:6.0f} GB/s", flush=True)
 
 
+def bench_fp8abl():
+    """Lab ablations of the fp8 K loop (per-tile kernel, garbage results): full / no DMA / no fragment reloads / neither."""
+    for name, M, N, K in (("esm qkv b64", 65536, 7680, 2560), ("esm fc2 b64", 65536, 2560, 10240), ("square 8k", 8192, 8192, 8192)):
+        a, w = rand((M, K)), rand((N, K), scale=0.05)
+        a8, sa = ops.quant_rows_fp8(a)
+        w8, sw = ops.quant_rows_fp8(w)
+        fl = 2.0 * M * N * K / 1e9
+        res = [timeit(lambda t=t: ops.gemm_nt_fp8(a8, sa, w8, sw, None, n=N, k=K, epilogue=0, tile=t), iters=5, warm=2) for t in (256, 1001, 1002, 1003)]
+        print(f"fp8abl {name:12s}: full {fl / res[0]:7.1f} TF/s | no DMA {fl / res[1]:7.1f} | no LDS reads {fl / res[2]:7.1f} | neither {fl / res[3]:7.1f}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "norm"]
     print(torch.cuda.get_device_name(0), flush=True)
@@ -212,3 +223,5 @@ if __name__ == "__main__":
         bench_blas()
     if "fp8" in which:
         bench_fp8()
+    if "fp8abl" in which:
+        bench_fp8abl()
