@@ -66,6 +66,10 @@ def read_pass(directory):
 def main():
     root, out_path = sys.argv[1], sys.argv[2]
     label = sys.argv[3] if len(sys.argv) > 3 else ""
+    cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
+    sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
+    from p2t_hip import specs
+    workload = f"{cfg}/{specs.CONFIGS[cfg][3]}"                  # config / per-GPU batch of bench.py's default run
     merged = defaultdict(dict)
     for sub in sorted(os.listdir(root)):
         for fam, counters in read_pass(os.path.join(root, sub)).items():
@@ -73,7 +77,7 @@ def main():
                 merged[fam][cname] = {"avg": total / max(n, 1), "launches": n}
     out = {"source": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline --no-batch64-check; aggregated by tools/pmc_traffic.py",
-           "label": label, "kernel_src_sha16": kernel_src_sha16(),
+           "label": label, "kernel_src_sha16": kernel_src_sha16(), "workload": workload,
            "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE "
                     "reports half of wide coalesced reads; Infinity-Cache hits included)",
            "kernels": {}}
