@@ -45,7 +45,8 @@ enum {                                                     /* GEMM epilogues (p2
     P2T_EPI_SWIGLU = 3,     /* C[m, f] = silu(gate) * up, gate/up interleaved by 32 rows of W */
     P2T_EPI_STORE_F32 = 4,  /* C(f32) = acc (+ C if accumulate)                  */
     P2T_EPI_GELU_BWD = 5,   /* C = acc * gelu_erf'(Z), Z read from z (adapter backward) */
-    P2T_EPI_QKV_ROPE = 6    /* internal to the towers: bias + q-scale + rotary + head split, head_dim 64 */
+    P2T_EPI_QKV_ROPE = 6,   /* internal to the towers: bias + q-scale + rotary + head split, head_dim 64 */
+    P2T_EPI_GELU_FP8 = 7    /* p2t_gemm_nt_fp8 only: C(e4m3 bytes) = gelu_erf(acc + bias) * 2^-(row_scale[m] - 127) */
 };
 
 typedef void* p2t_stream;
@@ -101,18 +102,24 @@ size_t p2t_gemm_fix_workspace_bytes(void);
  * smallest power of two such that amax(row) / 2^e <= 448; q = e4m3_rne(x * 2^-e).  An all-zero row gets E = 127. */
 int p2t_quant_rows_fp8(const void* x, int dtype, int64_t ld_x, int64_t rows, int64_t cols, void* q, int64_t ld_q,
                        uint8_t* scale, p2t_stream stream);
-/* torch.nn.LayerNorm / LlamaRMSNorm of the f32 stream written directly in that format (no bf16 intermediate). */
+/* torch.nn.LayerNorm / LlamaRMSNorm of the f32 stream written directly in that format (no bf16 intermediate).
+ * bound_scale (LayerNorm only, may be NULL): E8M0 byte per row of the smallest power of two >= (||y_row||_2 * bound_w +
+ * bound_b) / 448, y the normalised row -- with bound_w >= max_n ||W_n||_2 and bound_b >= max_n |bias_n| of the projection
+ * that consumes y, a valid scale for every element of gelu(y W^T + bias) (Cauchy-Schwarz; |gelu(z)| <= |z|): the row scale
+ * P2T_EPI_GELU_FP8 needs BEFORE its GEMM runs. */
 int p2t_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* q, int64_t ld_q,
-                      uint8_t* scale, int64_t rows, int64_t cols, p2t_stream stream);
+                      uint8_t* scale, int64_t rows, int64_t cols, float bound_w, float bound_b, uint8_t* bound_scale,
+                      p2t_stream stream);
 int p2t_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale,
                     int64_t rows, int64_t cols, p2t_stream stream);
 /* C[M,N] = (A8 * 2^(a_scale-127))[M,K] * (W8 * 2^(w_scale-127))[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (both scales
  * applied by the instruction), fp32 accumulate, the epilogues of p2t_gemm_nt (all but GELU_BWD).  A8 / W8: e4m3 bytes,
  * row strides lda / ldw in BYTES (multiples of 16), K % 128 == 0 with the padding zeroed; a_scale [M], w_scale [N] E8M0
- * bytes.  tile: 0 auto, 128 / 256 = tile height in rows. */
+ * bytes.  tile: 0 auto, 128 / 256 = tile height in rows.  P2T_EPI_GELU_FP8: out is e4m3 bytes [M, ldc bytes] (columns N up to
+ * the next multiple of 128 zeroed), out_row_scale the E8M0 byte of every output row (an input: see p2t_layernorm_fp8). */
 int p2t_gemm_nt_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
                     const float* bias, void* out, int64_t ldc, void* z, int64_t M, int64_t N, int64_t K, int out_dtype,
-                    int epilogue, int accumulate, int tile, p2t_stream stream);
+                    int epilogue, int accumulate, int tile, const uint8_t* out_row_scale, p2t_stream stream);
 
 /* The QKV projection as the towers launch it for head_dim 64 / 128 (P2T_EPI_QKV_ROPE): acc + bias, query * q_scale
  * BEFORE the rotation (HF EsmSelfAttention.forward, modeling_esm.py:345,362-378: q_scale = head_dim^-1/2 and SDPA scale 1;
@@ -174,6 +181,10 @@ typedef struct {
     /* gemm_fp8 only: the four matrices above are then e4m3 bytes, row-major [N][ld], ld = K rounded up to 128 (zero
      * padded), quantised with p2t_quant_rows_fp8, and these are their E8M0 row scales [N] */
     const uint8_t* qkv_ws; const uint8_t* o_ws; const uint8_t* fc1_ws; const uint8_t* fc2_ws;
+    /* gemm_fp8, optional (0 = quantise the GELU output in a separate pass): upper bounds of max_n ||fc1_w[n]||_2 (of the
+     * weights the GEMM multiplies with, i.e. after quantisation) and of max_n |fc1_b[n]|; with them the FFN-up GEMM writes
+     * its GELU output directly as e4m3 under the per-token bound scale of p2t_layernorm_fp8 */
+    float fc1_wnorm_bound, fc1_babs_bound;
 } p2t_esm2_layer;
 
 typedef struct {

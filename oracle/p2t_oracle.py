@@ -75,14 +75,34 @@ def quant_rows_e4m3(x: np.ndarray):
     return (q * scale).astype(F32), E, q
 
 
+FP8_OPERAND_GROWTH = (1.0 + 2.0 ** -4) ** 2      # e4m3 rounding enlarges an element by at most 2^-4, relative: two operands
+
+
+def gelu_bound_scale(h: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """E8M0 byte per row of the scale under which gelu(h W^T + b) is stored as e4m3 when the FFN-up GEMM writes fp8 directly
+    (csrc/quant.hip norm_fp8_kernel `bound_scale`, csrc/epilogue.h EpiGeluFp8): |gelu(z)| <= |z| <= ||h_row||_2 max_n ||W_n||_2
+    + max_n |b_n| (Cauchy-Schwarz), the weight norm inflated by FP8_OPERAND_GROWTH for the rounded operands."""
+    bw = F32(np.sqrt((w.astype(F32) ** 2).sum(-1, dtype=F32)).max() * FP8_OPERAND_GROWTH)
+    bb = F32(np.abs(b).max())
+    hn = np.sqrt((h.astype(F32) ** 2).sum(-1, dtype=F32)).astype(F32)
+    return e8m0_of_amax((hn.astype(np.float64) * np.float64(bw) + np.float64(bb)).astype(F32))
+
+
+def quant_rows_e4m3_scaled(x: np.ndarray, E: np.ndarray) -> np.ndarray:
+    """e4m3 storage of x under GIVEN row scales (E8M0 bytes) -> dequantised f32 values."""
+    scale = np.ldexp(F32(1.0), E.astype(np.int32) - 127).astype(F32)[..., None]
+    return (e4m3_round(np.ascontiguousarray(x, dtype=F32) / scale) * scale).astype(F32)
+
+
 class Precision:
     """identity (fp32 oracle); "bf16": bf16 rounding where the HIP bf16 path stores bf16; "fp8": the same, plus e4m3
     row-quantised operands (weights per output channel, activations per token) in the tower GEMMs -- `g` is applied to
     the two operands of every tower projection, `q` to everything the bf16 path rounds."""
 
-    def __init__(self, kind: str = "f32"):
+    def __init__(self, kind: str = "f32", fused_gelu: bool = True):
         assert kind in ("f32", "bf16", "fp8")
         self.kind = kind
+        self.fused_gelu = fused_gelu and kind == "fp8"    # ESM FFN-up output stored as e4m3 under the bound scale (no bf16 copy)
 
     def q(self, x):           # "quantise a stored activation / weight"
         return x if self.kind == "f32" else _bf16(x)
@@ -97,6 +117,7 @@ class Precision:
 FP32 = Precision("f32")
 BF16 = Precision("bf16")
 FP8 = Precision("fp8")
+FP8_UNFUSED = Precision("fp8", fused_gelu=False)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -238,7 +259,12 @@ def esm2_layer(spec, W, i, x, key_bias, cos, sin, prec: Precision = FP32, prefix
     o = g_(q_(attention_heads(q, k, v, key_bias, 1.0, prec).reshape(B * T, H)))     # ESM:310-317, scale 1.0
     x = x + lin("attention.output.dense", o).reshape(B, T, H)               # ESM:399-409
     h = prec.a(layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], spec.layer_norm_eps))
-    f = g_(q_(gelu_erf(lin("intermediate.dense", g_(h.reshape(B * T, H))))))   # ESM:442-450
+    z = lin("intermediate.dense", g_(h.reshape(B * T, H)))                    # ESM:442-450
+    if prec.fused_gelu:
+        E = gelu_bound_scale(h.reshape(B * T, H), q_(W[p + "intermediate.dense.weight"]), W[p + "intermediate.dense.bias"])
+        f = quant_rows_e4m3_scaled(gelu_erf(z), E)
+    else:
+        f = g_(q_(gelu_erf(z)))
     x = x + lin("output.dense", f).reshape(B, T, H)                          # ESM:453-463
     return x.astype(F32)
 

@@ -30,6 +30,7 @@ struct EpiParams {
     int seq, nh, nkv;
     int head_dim;           // 64, or 128 with the packed row order of include/p2t_hip.h (p2t_llama_layer)
     float q_scale;
+    const uint8_t* row_scale = nullptr;   // GELU_FP8: E8M0 scale byte of every OUTPUT row (known before the GEMM runs)
 };
 
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t idx, float p) {
@@ -129,6 +130,35 @@ struct EpiGelu {
             zeroW<W>(r);
             storeW<W>(o, r);
             if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, r);
+        }
+    }
+    P2T_EPI_APPLY2
+};
+
+// fp8 towers: C = e4m3(gelu_erf(acc + bias) * 2^-(E_m - 127)) with the row's E8M0 scale byte E_m given (p.row_scale): the
+// output feeds the next fp8 GEMM directly, no bf16 copy and no quantise pass.  E_m must bound the row (quant.hip derives it
+// from the Cauchy-Schwarz bound of the pre-activation); out is bytes, ldc in bytes.
+__device__ __forceinline__ unsigned epi_pack_fp8x4(float a, float b, float c, float d) {
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+struct EpiGeluFp8 {
+    static constexpr bool kRmw = false;
+    static constexpr int kMinOps = 2;
+    template <int W>
+    __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
+        static_assert(W == 8, "fp8 output: MFMA kernels only (8 consecutive columns per lane)");
+        uint8_t* o = (uint8_t*)p.out + m * p.ldc + n;
+        if (n < p.N) {
+            const float inv = __uint_as_float((unsigned)(254 - (int)p.row_scale[m]) << 23);      // 2^-(E - 127), exact
+            float r[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) r[j] = gelu_erf(v[j] + b[j]) * inv;
+            *reinterpret_cast<uint2*>(o) = make_uint2(epi_pack_fp8x4(r[0], r[1], r[2], r[3]), epi_pack_fp8x4(r[4], r[5], r[6], r[7]));
+        } else if (n < p.n_zero) {
+            *reinterpret_cast<uint2*>(o) = make_uint2(0u, 0u);
         }
     }
     P2T_EPI_APPLY2

@@ -58,7 +58,7 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
                 "gemm_nt: EPI_QKV_ROPE needs head_dim 64 or 128 outputs, the rotary table and M = B * seq");
     if (a.dtype == P2T_FP8)
         P2T_REQUIRE(a.a_scale && a.w_scale && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && (uintptr_t)a.A % 16 == 0 &&
-                        (uintptr_t)a.W % 16 == 0 && a.epilogue != P2T_EPI_GELU_BWD,
+                        (uintptr_t)a.W % 16 == 0 && a.epilogue != P2T_EPI_GELU_BWD && (a.epilogue != P2T_EPI_GELU_FP8 || a.out_row_scale),
                     "gemm_nt (fp8): needs both row-scale arrays, K %% 128 == 0 (zero padded), 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)",
                     (long long)a.K, (long long)a.lda, (long long)a.ldw);
     P2T_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.ldc % 4 == 0 && a.lda >= a.K && a.ldw >= a.K,
@@ -71,6 +71,10 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     P2T_REQUIRE(a.epilogue != P2T_EPI_GELU_BWD || a.z, "gemm_nt: EPI_GELU_BWD needs z");
 
     int n_zero = n_out;
+    if (a.epilogue == P2T_EPI_GELU_FP8) {
+        P2T_REQUIRE(a.dtype == P2T_FP8 && a.out_row_scale && a.ldc % 8 == 0, "gemm_nt: EPI_GELU_FP8 needs the fp8 kernel, the output row scales and ldc %% 8 == 0");
+        n_zero = (int)(round_up(n_out, 128) < a.ldc ? round_up(n_out, 128) : a.ldc);
+    }
     if (a.epilogue == P2T_EPI_STORE || a.epilogue == P2T_EPI_GELU || swiglu || a.epilogue == P2T_EPI_GELU_BWD) {
         n_zero = a.n_zero >= 0 ? a.n_zero : (int)(round_up(n_out, 64) < a.ldc ? round_up(n_out, 64) : a.ldc);
         if (n_zero < n_out) n_zero = n_out;
@@ -81,6 +85,7 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     ep.bias = a.bias; ep.out = a.out; ep.z = a.z; ep.ldc = a.ldc; ep.M = a.M; ep.N = (int)a.N; ep.n_zero = n_zero;
     ep.accumulate = a.accumulate; ep.drop_p = a.drop_p; ep.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     ep.drop_seed = a.drop_seed;
+    ep.row_scale = a.out_row_scale;
     ep.cs = a.cs; ep.q = a.q; ep.k = a.k; ep.v = a.v; ep.seq = a.seq; ep.nh = a.nh; ep.nkv = a.nkv; ep.q_scale = a.q_scale; ep.head_dim = a.head_dim;
 
     if (a.dtype == P2T_FP8) {
@@ -167,9 +172,9 @@ extern "C" size_t p2t_gemm_fix_workspace_bytes(void) { return gemm_fix_workspace
 
 extern "C" int p2t_gemm_nt_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
                                const float* bias, void* out, int64_t ldc, void* z, int64_t M, int64_t N, int64_t K, int out_dtype,
-                               int epilogue, int accumulate, int tile, p2t_stream stream) {
+                               int epilogue, int accumulate, int tile, const uint8_t* out_row_scale, p2t_stream stream) {
     GemmArgs a{A, lda, W, ldw, bias, out, ldc, z, M, N, K, P2T_FP8, out_dtype, epilogue, accumulate, 1, -1, 0.f, 0, tile};
-    a.a_scale = a_scale; a.w_scale = w_scale;
+    a.a_scale = a_scale; a.w_scale = w_scale; a.out_row_scale = out_row_scale;
     return gemm_nt(a, (hipStream_t)stream);
 }
 

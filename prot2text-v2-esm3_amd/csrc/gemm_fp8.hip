@@ -268,6 +268,7 @@ int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const vo
         case P2T_EPI_SWIGLU: if (ob) P2T_FP8_CASE(EpiSwiglu<bf16_t>); else P2T_FP8_CASE(EpiSwiglu<float>);
         case P2T_EPI_STORE_F32: P2T_FP8_CASE(EpiF32);
         case P2T_EPI_QKV_ROPE: if (ob) P2T_FP8_CASE(EpiQkvRope<bf16_t>); else P2T_FP8_CASE(EpiQkvRope<float>);
+        case P2T_EPI_GELU_FP8: P2T_FP8_CASE(EpiGeluFp8);
     }
 #undef P2T_FP8_CASE
     set_error("gemm (fp8): unsupported epilogue %d", epilogue);

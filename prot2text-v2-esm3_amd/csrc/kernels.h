@@ -40,7 +40,7 @@ int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int
 int launch_quant_rows(const void* x, int dtype, int64_t ld_x, int64_t rows, int64_t cols, void* q, int64_t ld_q, uint8_t* scale,
                       hipStream_t s);
 int launch_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* q, int64_t ld_q,
-                         uint8_t* scale, int64_t rows, int64_t cols, hipStream_t s);
+                         uint8_t* scale, int64_t rows, int64_t cols, float bound_w, float bound_b, uint8_t* bound_scale, hipStream_t s);
 int launch_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale, int64_t rows,
                        int64_t cols, hipStream_t s);
 int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
@@ -62,6 +62,7 @@ struct GemmArgs {
     void* fix_ws = nullptr; size_t fix_bytes = 0; unsigned fix_epoch = 0;
     // dtype == P2T_FP8: A and W are e4m3 bytes (row strides in bytes), one E8M0 scale byte per row of each
     const uint8_t* a_scale = nullptr; const uint8_t* w_scale = nullptr;
+    const uint8_t* out_row_scale = nullptr;        // P2T_EPI_GELU_FP8: E8M0 byte of every output row
 };
 int gemm_nt(const GemmArgs& a, hipStream_t s);
 

@@ -90,7 +90,8 @@ int launch_quant_rows(const void* x, int dtype, int64_t ld_x, int64_t rows, int6
 template <int NV, bool RMS>
 __global__ void __launch_bounds__(256) norm_fp8_kernel(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ w,
                                                        const float* __restrict__ b, float eps, uint8_t* __restrict__ q, int64_t ld_q,
-                                                       uint8_t* __restrict__ scale, int64_t rows, int cols) {
+                                                       uint8_t* __restrict__ scale, int64_t rows, int cols, float bound_w, float bound_b,
+                                                       uint8_t* __restrict__ bound_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) norm_fp8_kernel(const float* __restrict__
         qq = wave_sum(qq);
         rstd = rsqrtf(qq / (float)cols + eps);
     }
-    float amax = 0.f;
+    float amax = 0.f, ssq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -148,10 +149,14 @@ __global__ void __launch_bounds__(256) norm_fp8_kernel(const float* __restrict__
                 for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(v[i][j]));
+            for (int j = 0; j < 4; ++j) { amax = fmaxf(amax, fabsf(v[i][j])); ssq = fmaf(v[i][j], v[i][j], ssq); }
         }
     }
     amax = wave_max(amax);
+    if (bound_scale) {           // scale of the NEXT projection's gelu output, from the Cauchy-Schwarz bound of its pre-activation
+        ssq = wave_sum(ssq);
+        if (lane == 0) bound_scale[row] = (uint8_t)e8m0_of_amax(fmaf(sqrtf(ssq), bound_w, bound_b));
+    }
     const int E = e8m0_of_amax(amax);
     const float inv = pow2_neg(E);
     if (lane == 0) scale[row] = (uint8_t)E;
@@ -166,12 +171,12 @@ __global__ void __launch_bounds__(256) norm_fp8_kernel(const float* __restrict__
 
 template <bool RMS>
 static int launch_norm_fp8_t(const float* x, int64_t ld_x, const float* w, const float* b, float eps, uint8_t* q, int64_t ld_q,
-                             uint8_t* scale, int64_t rows, int64_t cols, hipStream_t s) {
+                             uint8_t* scale, int64_t rows, int64_t cols, float bound_w, float bound_b, uint8_t* bound_scale, hipStream_t s) {
     const dim3 grid((unsigned)ceil_div(rows, 4));
     const int64_t span = ld_q > cols ? ld_q : cols;
 #define P2T_NORM8_CASE(NV)                                                                                       \
     if (span <= (NV) * 256) {                                                                                    \
-        norm_fp8_kernel<NV, RMS><<<grid, 256, 0, s>>>(x, ld_x, w, b, eps, q, ld_q, scale, rows, (int)cols);       \
+        norm_fp8_kernel<NV, RMS><<<grid, 256, 0, s>>>(x, ld_x, w, b, eps, q, ld_q, scale, rows, (int)cols, bound_w, bound_b, bound_scale); \
         P2T_LAUNCH_CHECK();                                                                                      \
         return P2T_OK;                                                                                           \
     }
@@ -182,16 +187,16 @@ static int launch_norm_fp8_t(const float* x, int64_t ld_x, const float* w, const
 }
 
 int launch_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* q, int64_t ld_q,
-                         uint8_t* scale, int64_t rows, int64_t cols, hipStream_t s) {
+                         uint8_t* scale, int64_t rows, int64_t cols, float bound_w, float bound_b, uint8_t* bound_scale, hipStream_t s) {
     if (rows == 0) return P2T_OK;
     P2T_REQUIRE(cols % 4 == 0 && ld_q % 4 == 0 && ld_q >= cols, "layernorm (fp8 output): cols and ld_q must be multiples of 4");
-    return launch_norm_fp8_t<false>(x, ld_x, w, b, eps, (uint8_t*)q, ld_q, scale, rows, cols, s);
+    return launch_norm_fp8_t<false>(x, ld_x, w, b, eps, (uint8_t*)q, ld_q, scale, rows, cols, bound_w, bound_b, bound_scale, s);
 }
 int launch_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale, int64_t rows,
                        int64_t cols, hipStream_t s) {
     if (rows == 0) return P2T_OK;
     P2T_REQUIRE(cols % 4 == 0 && ld_q % 4 == 0 && ld_q >= cols, "rmsnorm (fp8 output): cols and ld_q must be multiples of 4");
-    return launch_norm_fp8_t<true>(x, ld_x, w, nullptr, eps, (uint8_t*)q, ld_q, scale, rows, cols, s);
+    return launch_norm_fp8_t<true>(x, ld_x, w, nullptr, eps, (uint8_t*)q, ld_q, scale, rows, cols, 0.f, 0.f, nullptr, s);
 }
 
 }  // namespace p2t
@@ -205,9 +210,10 @@ extern "C" int p2t_quant_rows_fp8(const void* x, int dtype, int64_t ld_x, int64_
 }
 
 extern "C" int p2t_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* q, int64_t ld_q,
-                                 uint8_t* scale, int64_t rows, int64_t cols, p2t_stream stream) {
-    P2T_REQUIRE(x && w && b && q && scale && rows >= 0 && cols > 0, "p2t_layernorm_fp8: bad arguments");
-    return launch_layernorm_fp8(x, ld_x, w, b, eps, q, ld_q, scale, rows, cols, (hipStream_t)stream);
+                                 uint8_t* scale, int64_t rows, int64_t cols, float bound_w, float bound_b, uint8_t* bound_scale,
+                                 p2t_stream stream) {
+    P2T_REQUIRE(x && w && b && q && scale && rows >= 0 && cols > 0 && bound_w >= 0.f && bound_b >= 0.f, "p2t_layernorm_fp8: bad arguments");
+    return launch_layernorm_fp8(x, ld_x, w, b, eps, q, ld_q, scale, rows, cols, bound_w, bound_b, bound_scale, (hipStream_t)stream);
 }
 
 extern "C" int p2t_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale,

@@ -146,7 +146,7 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
             g.a_scale = as; g.w_scale = ws;
             return g;
         };
-        P2T_TRY(launch_layernorm_fp8(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        P2T_TRY(launch_layernorm_fp8(b.x, H, L.ln1_w, L.ln1_b, c->layer_norm_eps, b.hq, Hq, b.hs, M, H, 0.f, 0.f, nullptr, s));
         if (d == 64) {
             GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, L.qkv_b, nullptr, 0, 3 * H, Hq, dt, P2T_EPI_QKV_ROPE);
             g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nh; g1.q_scale = q_scale;
@@ -161,10 +161,21 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
         P2T_TRY(launch_quant_rows(b.ao, dt, Hp, M, H, b.aoq, Hq, b.aos, s));
         GemmArgs g2 = fp8(b.aoq, Hq, b.aos, L.o_w, L.o_ws, L.o_b, b.x, H, H, Hq, P2T_F32, P2T_EPI_RESID);
         P2T_TRY(gemm_nt(g2, s));
-        P2T_TRY(launch_layernorm_fp8(b.x, H, L.ln2_w, L.ln2_b, c->layer_norm_eps, b.hq, Hq, b.hs, M, H, s));
-        GemmArgs g3 = fp8(b.hq, Hq, b.hs, L.fc1_w, L.fc1_ws, L.fc1_b, b.ffn, Fp, F, Hq, dt, P2T_EPI_GELU);
-        P2T_TRY(gemm_nt(g3, s));
-        P2T_TRY(launch_quant_rows(b.ffn, dt, Fp, M, F, b.ffnq, Fq, b.ffns, s));
+        // FFN-up writes its GELU output straight as e4m3 when the layer carries the weight-norm bound: the per-token scale is
+        // then known before the GEMM runs (||LN(x)||_2 * max_n ||W_n||_2 + max |bias| bounds every element of the row),
+        // derived by the LayerNorm kernel that already holds the row; otherwise: bf16 output + one quantise pass
+        const bool fused_q = L.fc1_wnorm_bound > 0.f;
+        P2T_TRY(launch_layernorm_fp8(b.x, H, L.ln2_w, L.ln2_b, c->layer_norm_eps, b.hq, Hq, b.hs, M, H, L.fc1_wnorm_bound, L.fc1_babs_bound,
+                                     fused_q ? b.ffns : nullptr, s));
+        if (fused_q) {
+            GemmArgs g3 = fp8(b.hq, Hq, b.hs, L.fc1_w, L.fc1_ws, L.fc1_b, b.ffnq, Fq, F, Hq, dt, P2T_EPI_GELU_FP8);
+            g3.out_row_scale = b.ffns;
+            P2T_TRY(gemm_nt(g3, s));
+        } else {
+            GemmArgs g3 = fp8(b.hq, Hq, b.hs, L.fc1_w, L.fc1_ws, L.fc1_b, b.ffn, Fp, F, Hq, dt, P2T_EPI_GELU);
+            P2T_TRY(gemm_nt(g3, s));
+            P2T_TRY(launch_quant_rows(b.ffn, dt, Fp, M, F, b.ffnq, Fq, b.ffns, s));
+        }
         GemmArgs g4 = fp8(b.ffnq, Fq, b.ffns, L.fc2_w, L.fc2_ws, L.fc2_b, b.x, H, H, Fq, P2T_F32, P2T_EPI_RESID);
         P2T_TRY(gemm_nt(g4, s));
     }

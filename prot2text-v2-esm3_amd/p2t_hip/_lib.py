@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("P2T_HIP_LIB") or os.path.join(_HERE, "lib", "libp2t_h
 F32, BF16, FP8 = 0, 1, 2
 READOUT = {"last": 0, "mean": 1, "std": 2, "mix": 3}
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_SWIGLU, EPI_STORE_F32, EPI_GELU_BWD = range(6)
+EPI_GELU_FP8 = 7
 
 
 class P2TError(RuntimeError):
@@ -39,7 +40,8 @@ class EsmConfigC(C.Structure):
 
 class EsmLayerC(C.Structure):
     _fields_ = [(n, vp) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_w", "ln1_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                                  "ln2_w", "ln2_b", "qkv_ws", "o_ws", "fc1_ws", "fc2_ws")]
+                                  "ln2_w", "ln2_b", "qkv_ws", "o_ws", "fc1_ws", "fc2_ws")] + \
+               [("fc1_wnorm_bound", f32), ("fc1_babs_bound", f32)]
 
 
 class EsmWeightsC(C.Structure):
@@ -94,9 +96,9 @@ SIGNATURES = {
     "p2t_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32, vp, sz, C.c_uint, vp]),
     "p2t_gemm_fix_workspace_bytes": (sz, []),
     "p2t_quant_rows_fp8": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, vp]),
-    "p2t_layernorm_fp8": (i32, [vp, i64, vp, vp, f32, vp, i64, vp, i64, i64, vp]),
+    "p2t_layernorm_fp8": (i32, [vp, i64, vp, vp, f32, vp, i64, vp, i64, i64, f32, f32, vp, vp]),
     "p2t_rmsnorm_fp8": (i32, [vp, i64, vp, f32, vp, i64, vp, i64, i64, vp]),
-    "p2t_gemm_nt_fp8": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, vp]),
+    "p2t_gemm_nt_fp8": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "p2t_gemm_qkv_rope": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, sz,
                                 C.c_uint, vp]),
     "p2t_layernorm": (i32, [vp, i64, vp, vp, f32, vp, i64, i64, i64, i32, vp]),

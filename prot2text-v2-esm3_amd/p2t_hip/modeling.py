@@ -50,10 +50,14 @@ def _build_tree(root: nn.Module, tensors, dtype, device, requires_grad=False):
 
 
 def _init_tree(root: nn.Module, std: float = 0.02):
-    """Random init in the spirit of HF `_init_weights`: N(0, std) matrices, zero biases, unit norms."""
+    """Random init in the spirit of HF `_init_weights`: matrices of standard deviation std, zero biases, unit norms.  On the
+    GPU the matrices come from the library's own counter-hash fill (one pass at HBM rate, no ATen RNG kernels: a 3B + 8B model
+    initialises in a fraction of a second and a rocprof trace of a run holds this library's kernels only)."""
     with torch.no_grad():
         for name, p in root.named_parameters():
-            if p.dim() == 2:
+            if p.dim() == 2 and p.is_cuda:
+                ops.fill_hash_(p.data, 0x1217, "init." + name, std * 3.0 ** 0.5)        # uniform(-a, a) has std a / sqrt(3)
+            elif p.dim() == 2:
                 p.normal_(0.0, std)
             elif name.endswith("bias"):
                 p.zero_()
@@ -137,6 +141,7 @@ class EsmEncoder(nn.Module):
         _init_tree(self)
         self._engine = None
         self.gemm_fp8 = False            # True: the four projections of every layer run on the fp8 MFMA kernel
+        self.fp8_fused_gelu = True       # fp8: FFN-up writes e4m3 directly under the per-token bound scale (False: bf16 + quantise pass)
         self._ws = _Workspace()
         self._register_load_state_dict_pre_hook(self._remap_legacy_inv_freq)
         self.register_load_state_dict_post_hook(lambda module, _incompatible: module.invalidate_engine())
@@ -175,12 +180,18 @@ class EsmEncoder(nn.Module):
                      fc1_w=_pad_cols(P[p + "intermediate.dense.weight"], Hp, dt), fc1_b=_f32(P[p + "intermediate.dense.bias"]),
                      fc2_w=_pad_cols(P[p + "output.dense.weight"], Fp, dt), fc2_b=_f32(P[p + "output.dense.bias"]),
                      ln2_w=_f32(P[p + "LayerNorm.weight"]), ln2_b=_f32(P[p + "LayerNorm.bias"]))
+            bounds = None
             if self.gemm_fp8:           # e4m3 bytes + one E8M0 scale per output channel (include/p2t_hip.h, p2t_esm2_layer)
+                # bound of the FFN-up pre-activation (Cauchy-Schwarz): max_n ||W_n||_2 -- inflated by (1 + 2^-4)^2 because the
+                # GEMM multiplies e4m3-rounded operands, each element up to 2^-4 larger than its source -- and max_n |b_n|
+                bounds = (float(t["fc1_w"][:, :H].float().norm(dim=1).max()) * (1.0 + 2.0 ** -4) ** 2, float(t["fc1_b"].abs().max()))
                 for name, kdim in (("qkv", H), ("o", H), ("fc1", H), ("fc2", F)):
                     t[name + "_w"], t[name + "_ws"] = _quant_fp8(t[name + "_w"], kdim)
             keep.append(t)
             for k, v in t.items():
                 setattr(layers[i], k, v.data_ptr())
+            if bounds is not None and self.fp8_fused_gelu:
+                layers[i].fc1_wnorm_bound, layers[i].fc1_babs_bound = bounds
         fw, fb = _f32(P["encoder.emb_layer_norm_after.weight"]), _f32(P["encoder.emb_layer_norm_after.bias"])
         emb = P["embeddings.word_embeddings.weight"].detach().contiguous()
         inv = self.rotary_embeddings.inv_freq.detach().float().contiguous()

@@ -123,23 +123,29 @@ def quant_rows_fp8(x: torch.Tensor, cols: int | None = None, ld_q: int | None = 
     return q, sc
 
 
-def norm_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, eps: float, ld_q: int | None = None):
-    """LayerNorm (b given) or RMSNorm (b None) of the f32 stream, written as e4m3 + E8M0 row scales."""
+def norm_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, eps: float, ld_q: int | None = None,
+             bound: tuple[float, float] | None = None):
+    """LayerNorm (b given) or RMSNorm (b None) of the f32 stream, written as e4m3 + E8M0 row scales.  bound = (w_norm_max,
+    b_abs_max) of the projection that follows (LayerNorm only): also returns the per-row bound scale bytes for its GELU output."""
     _chk(x.dtype == torch.float32 and x.dim() == 2, "norm_fp8: x must be f32 [rows, cols]")
     rows, cols = x.shape
     ld_q = round_up(cols, 128) if ld_q is None else ld_q
     q = torch.empty((rows, ld_q), dtype=torch.uint8, device=x.device)
     sc = torch.empty((rows,), dtype=torch.uint8, device=x.device)
     if b is not None:
-        call("p2t_layernorm_fp8", ptr(x), x.stride(0), ptr(w), ptr(b), float(eps), ptr(q), ld_q, ptr(sc), rows, cols, stream())
-    else:
-        call("p2t_rmsnorm_fp8", ptr(x), x.stride(0), ptr(w), float(eps), ptr(q), ld_q, ptr(sc), rows, cols, stream())
+        bs = torch.empty((rows,), dtype=torch.uint8, device=x.device) if bound is not None else None
+        call("p2t_layernorm_fp8", ptr(x), x.stride(0), ptr(w), ptr(b), float(eps), ptr(q), ld_q, ptr(sc), rows, cols,
+             float(bound[0]) if bound else 0.0, float(bound[1]) if bound else 0.0, ptr(bs), stream())
+        return (q, sc, bs) if bound is not None else (q, sc)
+    _chk(bound is None, "norm_fp8: the bound scale is a LayerNorm output")
+    call("p2t_rmsnorm_fp8", ptr(x), x.stride(0), ptr(w), float(eps), ptr(q), ld_q, ptr(sc), rows, cols, stream())
     return q, sc
 
 
 def gemm_nt_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: torch.Tensor | None = None, *,
                 n: int | None = None, k: int | None = None, epilogue: int = _lib.EPI_STORE, out: torch.Tensor | None = None,
-                out_dtype: torch.dtype = torch.bfloat16, z: torch.Tensor | None = None, tile: int = 0) -> torch.Tensor:
+                out_dtype: torch.dtype = torch.bfloat16, z: torch.Tensor | None = None, tile: int = 0,
+                out_row_scale: torch.Tensor | None = None) -> torch.Tensor:
     """epilogue((a8 * 2^(a_scale-127)) @ (w8 * 2^(w_scale-127)).T) on the fp8 MFMA kernel; a8 [M, lda], w8 [>= n, ldw] uint8."""
     _chk(a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.dim() == 2 and w8.dim() == 2, "gemm_nt_fp8: uint8 (e4m3) operands")
     _chk(a_scale.dtype == torch.uint8 and w_scale.dtype == torch.uint8, "gemm_nt_fp8: uint8 (E8M0) row scales")
@@ -148,12 +154,19 @@ def gemm_nt_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_sca
     k = min(a8.shape[1], w8.shape[1]) if k is None else k
     _chk(a_scale.numel() >= M and w_scale.numel() >= n, "gemm_nt_fp8: one scale per row")
     n_out = n // 2 if epilogue == _lib.EPI_SWIGLU else n
+    if epilogue == _lib.EPI_GELU_FP8:
+        _chk(out_row_scale is not None and out_row_scale.dtype == torch.uint8 and out_row_scale.numel() >= M, "EPI_GELU_FP8: one E8M0 byte per output row")
+        if out is None:
+            out = torch.empty((M, round_up(n_out, 128)), dtype=torch.uint8, device=a8.device)
+        call("p2t_gemm_nt_fp8", ptr(a8), a8.stride(0), ptr(a_scale), ptr(w8), w8.stride(0), ptr(w_scale), ptr(bias), ptr(out), out.stride(0),
+             None, M, n, k, _lib.BF16, epilogue, 0, int(tile), ptr(out_row_scale), stream())
+        return out
     if out is None:
         od = torch.float32 if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else out_dtype
         ldc = n_out if epilogue in (_lib.EPI_RESID, _lib.EPI_STORE_F32) else round_up(n_out, 64)
         out = torch.empty((M, ldc), dtype=od, device=a8.device)
     call("p2t_gemm_nt_fp8", ptr(a8), a8.stride(0), ptr(a_scale), ptr(w8), w8.stride(0), ptr(w_scale), ptr(bias), ptr(out), out.stride(0),
-         ptr(z), M, n, k, dt_of(out), epilogue, 0, int(tile), stream())
+         ptr(z), M, n, k, dt_of(out), epilogue, 0, int(tile), None, stream())
     return out
 
 

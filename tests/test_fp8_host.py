@@ -42,3 +42,21 @@ def test_quant_rows_invariants():
     # power-of-two scales commute with the quantiser: a row times 2^k gives the same codes, scale shifted by k
     deq2, E2, q2 = O.quant_rows_e4m3(x * np.float32(8.0))
     assert np.array_equal(q2, q) and np.array_equal(E2.astype(int) - E.astype(int), np.where(np.abs(x).max(1) > 0, 3, 0))
+
+
+def test_gelu_bound_scale_bounds_every_row_and_mirrors_in_the_esm_layer():
+    """The FFN-up fp8 output scale (oracle gelu_bound_scale): a valid scale for every row (no element above 448 * 2^e), and
+    the fused / unfused oracle precisions differ only by that scale choice."""
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal((50, 96)).astype(np.float32) * np.exp(rng.standard_normal((50, 1))).astype(np.float32)
+    w = rng.standard_normal((200, 96)).astype(np.float32) * 0.3
+    b = rng.standard_normal(200).astype(np.float32)
+    hq, wq = O.quant_rows_e4m3(h)[0], O.quant_rows_e4m3(w)[0]
+    E = O.gelu_bound_scale(h, w, b)
+    f = O.gelu_erf(hq @ wq.T + b)
+    cap = 448.0 * np.exp2(E.astype(np.float64) - 127)
+    assert (np.abs(f).max(-1) <= cap).all()
+    deq = O.quant_rows_e4m3_scaled(f, E)
+    big = np.abs(f) > cap[:, None] * 2.0 ** -14          # e4m3 normals span 14 binades below the cap
+    assert (np.abs(deq - f)[big] <= np.abs(f)[big] * 2.0 ** -4 + 1e-30).all()
+    assert O.FP8.fused_gelu and not O.FP8_UNFUSED.fused_gelu and not O.BF16.fused_gelu

@@ -64,6 +64,50 @@ def test_norms_fp8_output(ops, cols):
         assert not to_np(q)[:, cols:].any()
 
 
+def test_layernorm_fp8_bound_scale(ops):
+    """The second scale byte the LayerNorm kernel emits: 2^e >= (||y||_2 bound_w + bound_b) / 448 by the same integer rule."""
+    rows, cols = 200, 640
+    x, w, b = rnd(6, "nb.x", (rows, cols), 2.0, 0.3), rnd(6, "nb.w", (cols,), 0.1, 1.0), rnd(6, "nb.b", (cols,), 0.1)
+    x *= np.exp(rnd(6, "nb.s", (rows, 1), 2.0)).astype(np.float32)
+    bw, bb = 1.37, 0.21
+    q, sc, bs = ops.norm_fp8(to_dev(x), to_dev(w), to_dev(b), 1e-5, bound=(bw, bb))
+    q0, sc0 = ops.norm_fp8(to_dev(x), to_dev(w), to_dev(b), 1e-5)
+    assert torch.equal(q, q0) and torch.equal(sc, sc0)
+    y = O.layer_norm(x, w, b, 1e-5)
+    amax = np.sqrt((y.astype(np.float64) ** 2).sum(-1)) * np.float32(bw) + np.float32(bb)
+    E = O.e8m0_of_amax(amax.astype(np.float32))
+    d = np.abs(to_np(bs).astype(int) - E.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.02          # a row whose bound sits on a power-of-two boundary may go either way
+
+
+@pytest.mark.parametrize("tile", [256, 128])
+@pytest.mark.parametrize("shape", [(300, 320, 128), (1000, 96, 256), (2048, 1184, 384), (700, 2560, 2560)])
+def test_gemm_fp8_gelu_fp8_epilogue(ops, tile, shape):
+    """EPI_GELU_FP8: e4m3 codes of gelu(acc + bias) under GIVEN row scales; codes may differ from numpy's only where the f32
+    value sits on a rounding boundary (accumulation order), so: dequantised values within half an e4m3 step, few codes differ."""
+    M, N, K = shape
+    a = rnd(51, "g8.a", (M, K), 1.0) * np.exp(rnd(51, "g8.as", (M, 1), 1.0)).astype(np.float32)
+    w = rnd(51, "g8.w", (N, K), 1.0) / np.float32(np.sqrt(K))
+    bias = rnd(51, "g8.b", (N,), 0.3)
+    a8, sa = ops.quant_rows_fp8(to_dev(a))
+    w8, sw = ops.quant_rows_fp8(to_dev(w))
+    da, dw = O.quant_rows_e4m3(a)[0], O.quant_rows_e4m3(w)[0]
+    E = O.gelu_bound_scale(da, dw / np.float32(O.FP8_OPERAND_GROWTH), bias)       # operands already rounded: no growth factor needed
+    ref_f = O.gelu_erf(da @ dw.T + bias)
+    assert np.abs(ref_f).max(-1).max() > 0 and (np.abs(ref_f).max(-1) <= 448 * np.exp2(E.astype(np.float32) - 127)).all(), "the bound holds"
+    ref = O.quant_rows_e4m3_scaled(ref_f, E)
+    out = ops.gemm_nt_fp8(a8, sa, w8, sw, to_dev(bias), n=N, k=a8.shape[1], epilogue=7, tile=tile, out_row_scale=to_dev(E))
+    assert out.dtype == torch.uint8 and out.shape == (M, (N + 127) // 128 * 128)
+    codes = to_np(out)
+    assert not codes[:, N:].any()
+    got = _decode(codes[:, :N]) * np.exp2(E.astype(np.float32) - 127)[:, None]
+    observe(f"gemm_fp8_gelu_fp8[{M}x{N}x{K},t{tile}]", rel(got, ref), 5e-3)
+    assert np.mean(got != ref) < 5e-3
+    # how much of e4m3's range the bound scale gives away (Cauchy-Schwarz is loose): recorded, not asserted
+    slack = np.log2(448 * np.exp2(E.astype(np.float32) - 127) / np.abs(ref_f).max(-1))
+    observe(f"gemm_fp8_gelu_fp8_slack_binades[{M}x{N}x{K},t{tile}]", float(slack.mean()), 12.0, "log2(bound / amax), mean over rows")
+
+
 def _gemm_ref(a, w, bias, epi, resid=None):
     acc = a.astype(np.float32) @ w.astype(np.float32).T
     if epi == EPI_SWIGLU:
@@ -200,6 +244,17 @@ def test_fp8_step_trains_and_is_padding_invariant():
     with torch.no_grad():
         pb = to_np(P.l2_normalize(P.get_sequence_embeddings(bf, b["protein_input_ids"], b["protein_attention_mask"])))
     observe("fp8_vs_bf16.protein[d64,3 layers]", rel(p0, pb), 1.5e-1)
+    # FFN-up output stored under the per-token bound scale (default) against the amax scale of a separate quantise pass:
+    # same distance to the bf16 towers (the bound gives binades of e4m3's range away, not mantissa bits)
+    enc = model.esm_encoder
+    enc.fp8_fused_gelu = False
+    enc.invalidate_engine()
+    with torch.no_grad():
+        pu = to_np(P.l2_normalize(P.get_sequence_embeddings(model, b["protein_input_ids"], b["protein_attention_mask"])))
+    enc.fp8_fused_gelu = True
+    enc.invalidate_engine()
+    observe("fp8_unfused_gelu_vs_bf16.protein[d64,3 layers]", rel(pu, pb), 1.5e-1)
+    observe("fp8_fused_vs_unfused_gelu.protein[d64,3 layers]", rel(p0, pu), 1.5e-1)
     tr = P.ContrastiveTrainer(model, num_segments=2, output_llm_layer=3, train_mode=False, lr=2e-4)
     first = float(to_np(tr.step(b))[0])
     assert all(bool(torch.isfinite(g).all()) for g in tr.g)
