@@ -45,7 +45,9 @@ def observe(name, value, tol, what="rel"):
     global _OBS_PATH, _TOL_TABLE
     if _TOL_TABLE is None:
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tolerances.json")
-        _TOL_TABLE = json.load(open(tp)) if os.path.exists(tp) else {}
+        # P2T_TOL_TABLE=0: inline tolerances only -- the run that re-measures after a numerics change, before
+        # tools/update_tolerances.py rewrites the table from it
+        _TOL_TABLE = json.load(open(tp)) if os.path.exists(tp) and os.environ.get("P2T_TOL_TABLE", "1") != "0" else {}
     inline_tol = float(tol)
     if name in _TOL_TABLE:
         tol = min(inline_tol, float(_TOL_TABLE[name]["tol"]))
