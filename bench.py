@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--segments", type=int, default=1, help="contrastive_num_segments")
     ap.add_argument("--eval-mode", action="store_true", help="no adapter dropout (default: train mode, p=0.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-policy", type=int, default=0, help="p2t_set_gemm_policy for A/B runs (0 = the library's default; include/p2t_hip.h)")
     ap.add_argument("--event-steps", type=int, default=3,
                     help="timed steps whose MFMA launches are bracketed by HIP events for the roofline block "
                          "(default: the last 3 of the timed steps -- the event records cost ~1.5 % of the step when on every launch; "
@@ -251,6 +252,8 @@ def main():
                          f"(one process per GPU; there is no CPU or shared-GPU fallback)")
     import p2t_hip as P
     from p2t_hip import _lib, specs, synth
+    if args.gemm_policy:
+        _lib.call("p2t_set_gemm_policy", int(args.gemm_policy))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
@@ -307,7 +310,7 @@ def main():
         f = specs.flops_per_sample(esm, llama, ad, Tp, Tt, 16, backward=True)
         value = world * B * args.steps / elapsed
         step_tflops = f["total"] * B * args.steps / elapsed / 1e12          # per GPU
-        # dominant kernel: the gemm_nt_mfma* family (one algorithm, three launch forms).  algorithmic GEMM FLOPs per sample = linear layers of both towers
+        # dominant kernel: the bf16 MFMA GEMM family (gemm_nt_w4_kernel, gemm_nt_mfma*: one algorithm, several launch forms; a HIP-event record = one kernel launch).  algorithmic GEMM FLOPs per sample = linear layers of both towers
         # + adapter fwd/bwd (everything except the attention score/value products)
         He, Le = esm.hidden_size, esm.num_hidden_layers
         attn_flops = Le * 4 * Tp * Tp * He + min(16, llama.num_hidden_layers) * 2 * (Tt + 1) * Tt * llama.hidden_size
@@ -340,7 +343,7 @@ def main():
                        "loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma",
                          "kernel": ("gemm_nt_fp8_kernel (e4m3 16x16x128 block-scaled MFMA GEMM, all epilogues)" if fp8 else
-                                    "gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: persistent / per-tile / split-K-tail variants, all epilogues)"),
+                                    "gemm_nt_w4_kernel + gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: four-wave persistent form, eight-wave persistent / per-tile / split-K-tail forms, all epilogues)"),
                          "achieved": round(achieved, 1), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), 4),
                          "frac_of_bf16_peak": round(achieved / PEAK_BF16_TFLOPS, 4),

@@ -68,7 +68,10 @@ int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes
 /* Launch-form override of the bf16 MFMA GEMM for experiments and tests (process-wide): 0 = measured default policy;
  * 128 / 256 = force the tile height (per-tile kernels); 1 = no split-K tail; 2 = per-tile kernels only; 3 = persistent
  * kernel with the split-K fix-up whenever possible; 4 = persistent, never the fix-up; 5 = persistent, partial round as
- * 128-row halves.  Results are identical up to the fp32 summation order. */
+ * 128-row halves (3 / 4 / 5: the eight-wave persistent kernel); 6 = 64-deep single-barrier skeleton (experiment);
+ * 7 = four-wave kernel, one tile per block; 8 = four-wave persistent kernel where eligible (what 0 picks too); 9 = the default policy without the four-wave form;
+ * 10 = four-wave persistent kernel, a partial last round as whole tiles.
+ * Results are identical up to the fp32 summation order. */
 int p2t_set_gemm_policy(int policy);
 
 /* ---------------------------------------------------------------- synthetic data (bench / tests) */

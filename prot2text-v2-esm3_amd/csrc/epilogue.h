@@ -75,13 +75,15 @@ template <int W> __device__ __forceinline__ void zeroW(float (&v)[W]) {
     for (int c = 0; c < W; ++c) v[c] = 0.f;
 }
 
-// Every functor: group(p, m, n, v, b) handles W consecutive columns starting at n; apply2 = both groups.
+// Every functor: group(p, m, n, v, b) handles W consecutive columns starting at n; apply2 = both groups.  IN: the caller
+// guarantees the tile lies inside the output (n + 32 + W <= N): no per-lane column checks, the epilogue of a tile is one
+// basic block the scheduler can interleave across rows.
 #define P2T_EPI_APPLY2                                                                                          \
-    template <int W>                                                                                            \
+    template <int W, bool IN = false>                                                                           \
     __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W],   \
                                                   const float (&v1)[W], const float (&b0)[W], const float (&b1)[W]) { \
-        group<W>(p, m, n, v0, b0);                                                                              \
-        group<W>(p, m, n + 32, v1, b1);                                                                         \
+        group<W, IN>(p, m, n, v0, b0);                                                                          \
+        group<W, IN>(p, m, n + 32, v1, b1);                                                                     \
     }
 
 // kMinOps (every functor): a LOWER bound of the vector-memory instructions one apply2<8> call issues on a tile that
@@ -93,11 +95,11 @@ template <typename Tout>
 struct EpiStore {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
         float r[W];
-        if (n < p.N) {
+        if (IN || n < p.N) {
 #pragma unroll
             for (int j = 0; j < W; ++j) r[j] = v[j] + b[j];
             storeW<W>(o, r);
@@ -109,27 +111,35 @@ struct EpiStore {
     P2T_EPI_APPLY2
 };
 
-template <typename Tout>
+// EXTRA: also dropout (p.drop_p > 0) and / or the pre-activation copy (p.z) -- the trained adapter's forward.  The towers'
+// FFN uses the plain form: no per-group branches, so the 16 erf evaluations of a row pair overlap.
+template <typename Tout, bool EXTRA = false>
 struct EpiGelu {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
         float zv[W], r[W];
-        if (n < p.N) {
+        if (IN || n < p.N) {
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 zv[j] = v[j] + b[j];
                 r[j] = gelu_erf_for<Tout>(zv[j]);
-                if (p.drop_p > 0.f) r[j] = dropout_keep(p.drop_seed, m * (int64_t)p.N + n + j, p.drop_p) ? r[j] * p.drop_scale : 0.f;
+                if constexpr (EXTRA) {
+                    if (p.drop_p > 0.f) r[j] = dropout_keep(p.drop_seed, m * (int64_t)p.N + n + j, p.drop_p) ? r[j] * p.drop_scale : 0.f;
+                }
             }
-            if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, zv);
+            if constexpr (EXTRA) {
+                if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, zv);
+            }
             storeW<W>(o, r);
         } else if (n < p.n_zero) {
             zeroW<W>(r);
             storeW<W>(o, r);
-            if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, r);
+            if constexpr (EXTRA) {
+                if (p.z) storeW<W>((Tout*)p.z + m * p.ldc + n, r);
+            }
         }
     }
     P2T_EPI_APPLY2
@@ -147,11 +157,11 @@ __device__ __forceinline__ unsigned epi_pack_fp8x4(float a, float b, float c, fl
 struct EpiGeluFp8 {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 2;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         static_assert(W == 8, "fp8 output: MFMA kernels only (8 consecutive columns per lane)");
         uint8_t* o = (uint8_t*)p.out + m * p.ldc + n;
-        if (n < p.N) {
+        if (IN || n < p.N) {
             const float inv = __uint_as_float((unsigned)(254 - (int)p.row_scale[m]) << 23);      // 2^-(E - 127), exact
             float r[W];
 #pragma unroll
@@ -169,11 +179,11 @@ template <typename Tout>
 struct EpiGeluBwd {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 4 * kStoreOps8<Tout>;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
         Tout* o = (Tout*)p.out + m * p.ldc + n;
         float zv[W], r[W];
-        if (n < p.N) {
+        if (IN || n < p.N) {
             loadW<W>((const Tout*)p.z + m * p.ldc + n, zv);
 #pragma unroll
             for (int j = 0; j < W; ++j) {
@@ -209,9 +219,9 @@ struct EpiResid {
         storeW<W>(o, r0);
         storeW<W>(o + 32, r1);
     }
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
-        if (n >= p.N) return;
+        if (!IN && n >= p.N) return;
         float* o = (float*)p.out + m * p.ldc + n;
         float r[W];
         loadW<W>(o, r);
@@ -226,9 +236,9 @@ struct EpiResid {
 struct EpiF32 {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 4;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void group(const EpiParams& p, int64_t m, int n, const float (&v)[W], const float (&b)[W]) {
-        if (n >= p.N) return;
+        if (!IN && n >= p.N) return;
         float* o = (float*)p.out + m * p.ldc + n;
         float r[W];
         if (p.accumulate) {
@@ -249,13 +259,13 @@ template <typename Tout>
 struct EpiSwiglu {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = kStoreOps8<Tout>;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&g)[W], const float (&u)[W],
                                                   const float (&b0)[W], const float (&b1)[W]) {
         const int f = (n >> 6) * 32 + (n & 31);
         Tout* o = (Tout*)p.out + m * p.ldc + f;
         float r[W];
-        if (n < p.N) {
+        if (IN || n < p.N) {
 #pragma unroll
             for (int j = 0; j < W; ++j) r[j] = silu(g[j]) * u[j];
             storeW<W>(o, r);
@@ -276,10 +286,10 @@ template <typename Tout>
 struct EpiQkvRope {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
-    template <int W>
+    template <int W, bool IN = false>
     __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
                                                   const float (&b0)[W], const float (&b1)[W]) {
-        if (n >= p.N) return;
+        if (!IN && n >= p.N) return;
         const int hd = p.head_dim, half = hd >> 1;
         const int blk = n >> 6;
         const int head = hd == 64 ? blk : blk >> 1;

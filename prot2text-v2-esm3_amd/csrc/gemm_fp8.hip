@@ -263,7 +263,7 @@ int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const vo
 #define P2T_FP8_CASE(E) return launch_shape8<E>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, ep, tile, s)
     switch (epilogue) {
         case P2T_EPI_STORE: if (ob) P2T_FP8_CASE(EpiStore<bf16_t>); else P2T_FP8_CASE(EpiStore<float>);
-        case P2T_EPI_GELU: if (ob) P2T_FP8_CASE(EpiGelu<bf16_t>); else P2T_FP8_CASE(EpiGelu<float>);
+        case P2T_EPI_GELU: { using GeluB = EpiGelu<bf16_t, true>; using GeluF = EpiGelu<float, true>; if (ob) P2T_FP8_CASE(GeluB); else P2T_FP8_CASE(GeluF); }
         case P2T_EPI_RESID: P2T_FP8_CASE(EpiResid);
         case P2T_EPI_SWIGLU: if (ob) P2T_FP8_CASE(EpiSwiglu<bf16_t>); else P2T_FP8_CASE(EpiSwiglu<float>);
         case P2T_EPI_STORE_F32: P2T_FP8_CASE(EpiF32);
@@ -291,7 +291,7 @@ int launch_gemm_bf16_k64(const void* A, int64_t lda, const void* W, int64_t ldw,
     const bool ob = out_dtype == P2T_BF16;
     switch (epilogue) {
         case P2T_EPI_STORE: return ob ? launch_k64<EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s) : launch_k64<EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
-        case P2T_EPI_GELU: return ob ? launch_k64<EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s) : launch_k64<EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+        case P2T_EPI_GELU: return ob ? launch_k64<EpiGelu<bf16_t, true>>(A, lda, W, ldw, M, N, K, n_cover, ep, s) : launch_k64<EpiGelu<float, true>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
         case P2T_EPI_RESID: return launch_k64<EpiResid>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
     }
     return P2T_ERR_UNSUPPORTED;

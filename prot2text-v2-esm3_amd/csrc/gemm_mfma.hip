@@ -33,16 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-// Split-K fix-up of the tail round (see gemm_nt_mfma_tail_kernel): one fp32 accumulator slab per tail tile in the
-// register order of the block (thread t, register quad i -> float4 slab[i * 512 + t]) and one flag word per tile.
-struct SplitFix {
-    float* slab;            // [n_tail][32][512] float4 = 256 KiB per tile
-    unsigned* flag;         // [n_tail], holds the epoch of the last completed producer
-    unsigned* timeout;      // set to 1 if a consumer ever gave up waiting (never expected; bounded spin)
-    unsigned epoch;         // unique per launch within one zeroing of `flag`
-};
-enum { TILE_FULL = 0, TILE_PRODUCE = 1, TILE_CONSUME = 2 };
-
 // One BM x 256 output tile at (m0, n0) over K range [k0, k0 + 32 ns).  smem: 4 * (BM + 256) * 64 bytes.
 template <int MT, typename Epi, int MODE = TILE_FULL>
 __device__ __forceinline__ void gemm_tile(char* smem, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
@@ -479,6 +469,14 @@ __global__ void __launch_bounds__(512)
     }
 }
 
+// gemm_w4.hip: persistent four-wave form over the first n_items tiles of the order of n_order tiles
+template <typename Epi>
+int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
+                           const EpiParams& ep, const SplitFix& fix, hipStream_t s);
+template <typename Epi>
+constexpr bool kHasW4 = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value || std::is_same<Epi, EpiResid>::value ||
+                        std::is_same<Epi, EpiQkvRope<bf16_t>>::value || std::is_same<Epi, EpiGelu<bf16_t>>::value || std::is_same<Epi, EpiSwiglu<bf16_t>>::value;
+
 template <int MT, typename Epi>
 static int launch_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                       const EpiParams& ep, hipStream_t s) {
@@ -523,13 +521,27 @@ template <typename Epi>
 static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover,
                         const EpiParams& ep, int tile, void* fix_ws, size_t fix_bytes, unsigned fix_epoch, hipStream_t s) {
     if (tile == 0) tile = g_gemm_policy.load(std::memory_order_relaxed);
+    const bool no_w4 = tile == 9;                           // 9: the default policy without the four-wave form (A/B runs)
+    if (no_w4) tile = 0;
     if (tile == 6) {                                        // experiment: 64-deep single-barrier skeleton of gemm_fp8.hip
         extern int launch_gemm_bf16_k64(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, hipStream_t);
         const int rc = launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, n_cover, std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiStore<float>>::value || std::is_same<Epi, EpiGelu<float>>::value ? P2T_F32 : P2T_BF16,
                                             std::is_same<Epi, EpiResid>::value ? P2T_EPI_RESID : (std::is_same<Epi, EpiGelu<bf16_t>>::value || std::is_same<Epi, EpiGelu<float>>::value ? P2T_EPI_GELU : (std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value ? P2T_EPI_STORE : -1)), ep, s);
         if (rc != P2T_ERR_UNSUPPORTED) return rc;
         tile = 0;
-    }   // 128 | 256: tile height; 1: no split-K tail; 2: no persistent kernel; 3 / 4 / 5 below
+    }
+    if (tile == 7) {                                        // four-wave form of the 256 x 256 tile (gemm_w4.hip), per-tile launch
+        extern int launch_gemm_w4(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, hipStream_t);
+        constexpr bool f32o = std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiStore<float>>::value;
+        constexpr int code = std::is_same<Epi, EpiResid>::value ? P2T_EPI_RESID
+                             : std::is_same<Epi, EpiGelu<bf16_t>>::value ? P2T_EPI_GELU
+                             : std::is_same<Epi, EpiQkvRope<bf16_t>>::value ? P2T_EPI_QKV_ROPE
+                             : (std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value) ? P2T_EPI_STORE : -1;
+        const int rc = launch_gemm_w4(A, lda, W, ldw, M, N, K, n_cover, f32o ? P2T_F32 : P2T_BF16, code, ep, s);
+        if (rc != P2T_ERR_UNSUPPORTED) return rc;
+        tile = 0;
+    }
+    // 128 | 256: tile height; 1: no split-K tail; 2: no persistent kernel; 3 / 4 / 5 below
     const int kCUs = cu_count();
     {
         // persistent kernel: shapes without edge tiles and at least one whole round of tiles.  tile: 0 / 3 = with the
@@ -544,7 +556,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
         // 0.4 % of the step; with it hot in the Infinity Cache, as in the micro-benchmark, the per-tile kernel is 6 % ahead)
         const int64_t rem = items % kCUs;
         const bool eligible = items >= kCUs && (ns & 3) == 0 && ns >= 12 && M % 256 == 0 && N % 256 == 0 && n_cover == N;
-        const bool pick = tile == 3 || tile == 4 || tile == 5 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
+        const bool pick = tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
         if (eligible && pick) {
             int64_t n_full = items, n_tail = 0;
             int half_tail = 0;
@@ -559,12 +571,31 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
                 fix.timeout = (unsigned*)((char*)fix_ws + 1024);
                 fix.slab = (float*)((char*)fix_ws + kFixHeader);
                 fix.epoch = fix_epoch;
-            } else if ((tile == 0 || tile == 5) && rem > 0 && rem <= 128 && 2 * rem <= kCUs) {
+            } else if ((tile == 0 || tile == 5 || tile == 8) && rem > 0 && rem <= 128 && 2 * rem <= kCUs) {
                 // K too short for split-K to pay: the leftover tiles as 128-row halves, one per block (measured cold, as in
                 // a step: QKV 7.5 rounds -4.6 %, o-proj 2.5 rounds -3.7 %; FFN-down K = 10240 stays split-K: 787 vs 818 us)
                 n_full = items - rem;
                 n_tail = rem;
                 half_tail = 1;
+            }
+            if constexpr (kHasW4<Epi>) {
+                // four-wave form (gemm_w4.hip): the tiles of a partial last round run as split-K pairs inside the same
+                // persistent stream (tile == 10: as whole tiles)
+                const bool w4 = !no_w4 && (tile == 0 || tile == 8 || tile == 10) && (int64_t)256 * (lda > ldw ? lda : ldw) * 2 < ((int64_t)1 << 32) && ns >= 8;
+                if (w4) {
+                    SplitFix f4{};
+                    int64_t t4 = 0;
+                    // measured cold (profiles/r02_microbench_w4.log): the pair form pays for long K (FFN-down K = 10240: 752 vs 821 us);
+                    // at K = 2560 an extra round of whole tiles is cheaper than the second ring fill + the slab (QKV 496 vs 521 us)
+                    if (tile != 10 && (tile == 8 || ns >= 192) && fix_ws && rem > 0 && 2 * rem <= kCUs && ns >= 16 && fix_bytes >= kFixHeader + (size_t)rem * kFixSlab) {
+                        t4 = rem;
+                        f4.flag = (unsigned*)fix_ws;
+                        f4.timeout = (unsigned*)((char*)fix_ws + 1024);
+                        f4.slab = (float*)((char*)fix_ws + kFixHeader);
+                        f4.epoch = fix_epoch;
+                    }
+                    return launch_gemm_w4_persist<Epi>(A, lda, W, ldw, M, N, K, (int)(items - t4), (int)t4, kCUs, ep, f4, s);
+                }
             }
             gemm_nt_mfma_persist_kernel<Epi><<<dim3(kCUs), 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K,
                                                                       (int)ceil_div(M, 256), (int)ceil_div(n_cover, 256),
@@ -572,7 +603,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
             P2T_LAUNCH_CHECK();
             return P2T_OK;
         }
-        if (tile == 2 || tile == 3 || tile == 4 || tile == 5) tile = 0;
+        if (tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10) tile = 0;
     }
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);
@@ -626,6 +657,9 @@ int launch_gemm_mfma(const void* A, int64_t lda, const void* W, int64_t ldw, int
             return ob ? launch_shape<EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
                       : launch_shape<EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_GELU:
+            if (ep.drop_p > 0.f || ep.z)
+                return ob ? launch_shape<EpiGelu<bf16_t, true>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
+                          : launch_shape<EpiGelu<float, true>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
             return ob ? launch_shape<EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s)
                       : launch_shape<EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, tile, fix_ws, fix_bytes, fix_epoch, s);
         case P2T_EPI_RESID:

@@ -86,8 +86,8 @@ static int dispatch_epi(const void* A, int64_t lda, const void* W, int64_t ldw, 
             return ob ? launch_simple_t<T, EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
                       : launch_simple_t<T, EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
         case P2T_EPI_GELU:
-            return ob ? launch_simple_t<T, EpiGelu<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
-                      : launch_simple_t<T, EpiGelu<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
+            return ob ? launch_simple_t<T, EpiGelu<bf16_t, true>>(A, lda, W, ldw, M, N, K, n_cover, ep, s)
+                      : launch_simple_t<T, EpiGelu<float, true>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
         case P2T_EPI_RESID:
             return launch_simple_t<T, EpiResid>(A, lda, W, ldw, M, N, K, n_cover, ep, s);
         case P2T_EPI_SWIGLU:

@@ -7,6 +7,17 @@
 
 namespace p2t {
 
+// Split-K fix-up of the tail round (gemm_mfma.hip gemm_nt_mfma_tail_kernel, gemm_w4.hip): one fp32 accumulator slab per tail tile in the
+// register order of the block (thread t, register quad i -> float4 slab[i * 512 + t]) and one flag word per tile.
+struct SplitFix {
+    float* slab;            // [n_tail][32][512] float4 = 256 KiB per tile
+    unsigned* flag;         // [n_tail], holds the epoch of the last completed producer
+    unsigned* timeout;      // set to 1 if a consumer ever gave up waiting (never expected; bounded spin)
+    unsigned epoch;         // unique per launch within one zeroing of `flag`
+};
+enum { TILE_FULL = 0, TILE_PRODUCE = 1, TILE_CONSUME = 2 };
+
+
 // (tm, tn) of work item `id` out of `n_items`: the 8 XCDs get contiguous chunks (bijective for any count),
 // inside a chunk GM row-tiles are walked column-major so neighbouring CUs share activation panels.
 __device__ __forceinline__ void tile_coords(int id, int n_items, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -24,9 +35,13 @@ __device__ __forceinline__ void tile_coords(int id, int n_items, int tiles_m, in
 // INTERIOR: the tile lies fully inside the output (no row / column checks, one basic block).  Read-modify-write
 // epilogues (Epi::kRmw) then fetch their operand for four rows at a time before the first add, so the HBM latency of
 // the residual read is paid twice per tile instead of once per row.
-template <int MT, typename Epi, bool INTERIOR = false>
+// ADD: `addend` holds a second set of accumulators of the same tile (split-K partner), quad (i, j) of this thread at
+// addend[(i * MT + j) * add_stride] -- added on the way into the epilogue, so the accumulator registers themselves are never
+// redefined under control flow (which costs the register allocator hundreds of spills); `poison` (0 or NaN) is added too.
+template <int MT, typename Epi, bool INTERIOR = false, bool ADD = false>
 __device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[4][MT], const EpiParams& ep, int64_t M, int N, int n_cover,
-                                              int64_t m0, int n0, int wm, int wn, int fr, int kg) {
+                                              int64_t m0, int n0, int wm, int wn, int fr, int kg, const float4* addend = nullptr,
+                                              int add_stride = 0, float poison = 0.f) {
     const int nb = n0 + wn * 64 + kg * 8;
     if (!INTERIOR && nb >= n_cover) return;
     float b0[8], b1[8];
@@ -36,7 +51,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[4][MT], const E
         if (INTERIOR || nb < N) loadW<8>(ep.bias + nb, b0);
         if (INTERIOR || nb + 32 < N) loadW<8>(ep.bias + nb + 32, b1);
     }
-    if constexpr (INTERIOR && Epi::kRmw && MT % 4 == 0) {
+    if constexpr (INTERIOR && Epi::kRmw && MT % 4 == 0 && !ADD) {
 #pragma unroll
         for (int jb = 0; jb < MT; jb += 4) {
             float r0[4][8], r1[4][8];
@@ -55,9 +70,17 @@ __device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[4][MT], const E
         for (int j = 0; j < MT; ++j) {
             const int64_t m = m0 + wm * MT * 16 + j * 16 + fr;
             if (!INTERIOR && m >= M) continue;
-            const float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
-            const float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-            Epi::template apply2<8>(ep, m, nb, v0, v1, b0, b1);
+            float v0[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3], acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+            float v1[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3], acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+            if constexpr (ADD) {
+                const float4 p0 = addend[(0 * MT + j) * add_stride], p1 = addend[(1 * MT + j) * add_stride];
+                const float4 p2 = addend[(2 * MT + j) * add_stride], p3 = addend[(3 * MT + j) * add_stride];
+                v0[0] += p0.x + poison; v0[1] += p0.y + poison; v0[2] += p0.z + poison; v0[3] += p0.w + poison;
+                v0[4] += p1.x + poison; v0[5] += p1.y + poison; v0[6] += p1.z + poison; v0[7] += p1.w + poison;
+                v1[0] += p2.x + poison; v1[1] += p2.y + poison; v1[2] += p2.z + poison; v1[3] += p2.w + poison;
+                v1[4] += p3.x + poison; v1[5] += p3.y + poison; v1[6] += p3.z + poison; v1[7] += p3.w + poison;
+            }
+            Epi::template apply2<8, INTERIOR>(ep, m, nb, v0, v1, b0, b1);
         }
     }
 }

@@ -19,134 +19,268 @@ namespace p2t {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-namespace {
-constexpr int w4_vm_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
-}
-
-template <typename Epi>
+// PERSIST: one block per CU walks the items blockIdx.x, + gridDim.x, ... < n_items of the tile order over n_items + n_tail tiles and
+// treats the K loops of consecutive tiles as ONE stream of stages: the last two stages of a tile issue the DMA of the next
+// tile's first two, and the epilogue's stores are never drained -- vmcnt completes in issue order, so the first stage after
+// an epilogue waits with a count that leaves the epilogue's operations in flight (Epi::kMinOps is a lower bound of them: the
+// persistent form only takes shapes without edge tiles, where every wave issues all of them).  Requires M % 256 == 0,
+// N % 256 == 0 == n_cover, K % 128 == 0, K >= 256.  !PERSIST: one tile per block, any M / N (rows clamped, edge epilogue).
+template <typename Epi, bool PERSIST>
 __global__ void __launch_bounds__(256)
     gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M, int N, int K,
-                      int tiles_m, int tiles_n, int n_cover, EpiParams ep) {
-    constexpr int MT = 8, NT = 8, SLOT = 512 * 64, NL = 8;
-    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+                      int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix) {
+    constexpr int MT = 8, NT = 8, BUF = 512 * 128, WOFF = 256 * 128, NL = 16;
+    constexpr int kEpiOps = 2 * MT * Epi::kMinOps;
+    constexpr int kExtCount = NL + kEpiOps > 63 ? 63 : NL + kEpiOps;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w >> 1, wn = w & 1;
-    const int ns = K >> 5;
+    const int nk = K >> 6;
 
+    int item = blockIdx.x;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
-    const int64_t m0 = (int64_t)tm * 256;
-    const int n0 = tn * 256;
+    const int n_order = n_items + n_tail;
+    tile_coords(item, n_order, tiles_m, tiles_n, tm, tn);
+    int64_t m0 = (int64_t)tm * 256;
+    int n0 = tn * 256;
 
-    // ---- staging: wave w owns rows [64 w, 64 w + 64) of both operand tiles: 4 + 4 pieces of 16 rows x 64 B per stage ----
-    const int schunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
-    const char* a_base = (const char*)(A + m0 * lda);
-    const char* w_base = (const char*)(W + (int64_t)n0 * ldw);
-    uint32_t a_voff[4], w_voff[4];
+    // ---- staging: one DMA instruction = 8 rows x 128 B (whole cache lines); wave w owns rows [64 w, 64 w + 64) of both
+    // operand tiles = 8 + 8 pieces per 64-deep stage.  LDS image: 128-byte rows, 16-byte chunk c of row r at chunk
+    // c ^ ((r >> 1) & 7) (conflict-free for the fragment reads below); the image is lane-linear, so the swizzle is applied to
+    // the SOURCE address. ----
+    const char* a_ptr = (const char*)(A + m0 * lda);          // DMA source of the next stage to issue (advances 128 B per stage)
+    const char* w_ptr = (const char*)(W + (int64_t)n0 * ldw);
+    uint32_t a_voff[8], w_voff[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int R = w * 64 + t * 16 + (lane >> 2), r = R & 63;
-        int64_t ar = m0 + R < M ? R : (int)(M - 1 - m0);
+    for (int t = 0; t < 8; ++t) {
+        const int R = w * 64 + t * 8 + (lane >> 3), r = R & 63;
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        int64_t ar = R;
         int wr = (R & ~63) + ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);      // permuted weight row
-        wr = n0 + wr < N ? wr : N - 1 - n0;
-        a_voff[t] = (uint32_t)(ar * lda + schunk * 8) * 2u;
-        w_voff[t] = (uint32_t)((int64_t)wr * ldw + schunk * 8) * 2u;
+        if (!PERSIST) {
+            ar = m0 + R < M ? R : (int)(M - 1 - m0);
+            wr = n0 + wr < N ? wr : N - 1 - n0;
+        }
+        a_voff[t] = (uint32_t)(ar * lda + c * 8) * 2u;
+        w_voff[t] = (uint32_t)((int64_t)wr * ldw + c * 8) * 2u;
     }
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
-    // LDS DMA in the saddr form from inline asm (see gemm_mfma.hip: the builtin makes LLVM turn counted waits into waits for zero)
-    auto dma = [&](int piece, int slot, int koff) {                  // piece 0..3: activation rows, 4..7: weight rows
-        const char* sb = (piece < 4 ? a_base : w_base) + koff * 2;
-        const uint32_t vo = piece < 4 ? a_voff[piece & 3] : w_voff[piece & 3];
-        const uint32_t lds = lds0 + slot * SLOT + (piece < 4 ? 0 : 256 * 64) + (w * 4 + (piece & 3)) * 1024;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(lds) : "memory");
-    };
 
     const int fr = lane & 15, kg = lane >> 4;
-    const int sw = (kg ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4;
-    const int x_off = (wm * 128 + fr) * 64 + sw;
-    const int w_off = 256 * 64 + (wn * 128 + fr) * 64 + sw;
+    const uint32_t f_off = fr * 128 + ((kg ^ ((fr >> 1) & 7)) << 4);        // K half 0; K half 1 is the same address ^ 64
+    const uint32_t x_addr = lds0 + wm * 128 * 128 + f_off, w_addr = lds0 + WOFF + wn * 128 * 128 + f_off;
 
-    f32x4 acc[2][4][MT];                // [64-column group of the wave][W fragment][activation fragment]
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];           // fragments of K half 0 / K half 1 of the current stage
 
-    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
-
-    // one 32-deep stage; FULL: stages s+1 .. s+4 all exist (branch-free)
-    auto step = [&](auto full, int s, const bf16x8 (&xc)[MT], const bf16x8 (&wc)[NT], bf16x8 (&xn)[MT], bf16x8 (&wnx)[NT]) {
-        constexpr bool FULL = decltype(full)::value;
-        const bool rd = FULL || s + 1 < ns, is = FULL || s + 4 < ns;
-        if (FULL) {
-            __builtin_amdgcn_s_waitcnt(w4_vm_imm(2 * NL));              // stage s+1 landed; s+2, s+3 may be in flight
-        } else if (s + 1 < ns) {
-            const int inflight = (ns - 1 < s + 3 ? ns - 1 : s + 3) - (s + 1);
-            if (inflight >= 2) __builtin_amdgcn_s_waitcnt(w4_vm_imm(2 * NL));
-            else if (inflight == 1) __builtin_amdgcn_s_waitcnt(w4_vm_imm(NL));
-            else __builtin_amdgcn_s_waitcnt(w4_vm_imm(0));
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const char* xs = smem + ((s + 1) & 3) * SLOT + x_off;
-        const char* ws = smem + ((s + 1) & 3) * SLOT + w_off;
-#pragma unroll
-        for (int p = 0; p < 32; ++p) {
-            if (p < 8) {
-                if (rd) wnx[p] = *reinterpret_cast<const bf16x8*>(ws + p * 1024);
-            } else if (p < 16) {
-                if (rd) xn[p - 8] = *reinterpret_cast<const bf16x8*>(xs + (p - 8) * 1024);
-            } else if (p < 24) {
-                if (is) dma(p - 16, s & 3, (s + 4) * 32);
-            }
-            const int j = p >> 2, i0 = (p & 3) * 2;
-            acc[i0 >> 2][i0 & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0], xc[j], acc[i0 >> 2][i0 & 3][j], 0, 0, 0);
-            acc[(i0 + 1) >> 2][(i0 + 1) & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[i0 + 1], xc[j], acc[(i0 + 1) >> 2][(i0 + 1) & 3][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): the next step's fragments are in registers
+    // The whole K loop is volatile inline asm, so the issue order below IS the program order: the compiler allocates
+    // registers and forms addresses, nothing else ("a" pins every accumulator quad to AGPRs, in place; left to itself the
+    // allocator shuffles accumulators between the register files with v_accvgpr copies and s_nop bubbles).
+    auto rd = [&](bf16x8& f, uint32_t addr, auto off) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(decltype(off)::value));
     };
+    auto mm = [&](auto first, f32x4& c, const bf16x8& a, const bf16x8& b) {
+        if constexpr (decltype(first)::value) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    };
+    // LDS DMA in the saddr form (see gemm_mfma.hip: the builtin makes LLVM turn counted waits into waits for zero)
+    auto dma1 = [&](int piece, int buf) {                               // piece 0..7: activation rows, 8..15: weight rows
+        const char* sb = piece < 8 ? a_ptr : w_ptr;
+        const uint32_t vo = piece < 8 ? a_voff[piece & 7] : w_voff[piece & 7];
+        const uint32_t lds = lds0 + buf * BUF + (piece < 8 ? 0 : WOFF) + (w * 8 + (piece & 7)) * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(lds) : "memory");
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    // One 64-deep stage s (buffer B = s & 1); its K-half-0 fragments are in (xa, wa).
+    //   first half : 64 MFMAs on K half 0 (FIRST: C = 0, the tile's accumulators start here); the 16 reads of K half 1
+    //                behind the first 16 pairs; once they have landed in every wave (lgkmcnt(0) + barrier) buffer B is free
+    //                and the DMA of stage s+2 starts into it (RT: only if `more`);
+    //   second half: 64 MFMAs on K half 1; stage s+1 has landed (vmcnt + barrier; it was issued a whole stage ago; `ext`:
+    //                the previous tile's epilogue operations sit between it and this stage's DMA), its K-half-0 fragments
+    //                are read into (xa, wa) behind pairs 4..19.
+    auto stage = [&](f32x4 (&acc)[2][4][MT], auto bufc, auto first, auto rt, bool ext, bool more) {
+        constexpr int B = decltype(bufc)::value;
+        constexpr bool RT = decltype(rt)::value;
+        using FI = decltype(first);
+        const uint32_t xs1 = (x_addr + B * BUF) ^ 64u, ws1 = (w_addr + B * BUF) ^ 64u;                 // K half 1 of this stage
+        const uint32_t xs0 = x_addr + (B ^ 1) * BUF, ws0 = w_addr + (B ^ 1) * BUF;                     // K half 0 of the next one
+#define P2T_W4_PAIR(FF, WF, XF, P)                                                                            \
+        mm(FF{}, acc[(((P) & 3) * 2) >> 2][(((P) & 3) * 2) & 3][(P) >> 2], WF[((P) & 3) * 2], XF[(P) >> 2]);   \
+        mm(FF{}, acc[(((P) & 3) * 2 + 1) >> 2][(((P) & 3) * 2 + 1) & 3][(P) >> 2], WF[((P) & 3) * 2 + 1], XF[(P) >> 2]);
+#define P2T_W4_R1W(I) rd(wb[I], ws1, std::integral_constant<int, (I) * 2048>{});
+#define P2T_W4_R1X(J) rd(xb[J], xs1, std::integral_constant<int, (J) * 2048>{});
+#define P2T_W4_R0W(I) rd(wa[I], ws0, std::integral_constant<int, (I) * 2048>{});
+#define P2T_W4_R0X(J) rd(xa[J], xs0, std::integral_constant<int, (J) * 2048>{});
+#define P2T_W4_G(Q) if (!RT || more) dma1(Q, B);
+        P2T_W4_R1W(0) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1X(0) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 3)
+        P2T_W4_R1W(3) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1W(4) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 7)
+        P2T_W4_R1X(2) P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_R1W(7) P2T_W4_PAIR(FI, wa, xa, 10) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 11)
+        P2T_W4_R1X(4) P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_R1X(6) P2T_W4_PAIR(FI, wa, xa, 14) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 15)
+        P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_PAIR(FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        P2T_W4_G(0) P2T_W4_PAIR(FI, wa, xa, 20) P2T_W4_G(1) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_G(2) P2T_W4_PAIR(FI, wa, xa, 22) P2T_W4_G(3) P2T_W4_PAIR(FI, wa, xa, 23)
+        P2T_W4_G(4) P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_G(5) P2T_W4_PAIR(FI, wa, xa, 25) P2T_W4_G(6) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_G(7) P2T_W4_PAIR(FI, wa, xa, 27)
+        P2T_W4_G(8) P2T_W4_PAIR(FI, wa, xa, 28) P2T_W4_G(9) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_G(10) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_G(11) P2T_W4_PAIR(FI, wa, xa, 31)
+        P2T_W4_G(12) P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_G(13) P2T_W4_PAIR(F, wb, xb, 1) P2T_W4_G(14) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_G(15) P2T_W4_PAIR(F, wb, xb, 3)
+        a_ptr += 128; w_ptr += 128;
+        if (RT && !more) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (FI::value && ext) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kExtCount) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+        P2T_W4_R0W(0) P2T_W4_PAIR(F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_PAIR(F, wb, xb, 7)
+        P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_PAIR(F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
+        P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_PAIR(F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
+        P2T_W4_R0X(4) P2T_W4_PAIR(F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_PAIR(F, wb, xb, 19)
+        P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_PAIR(F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23) P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_PAIR(F, wb, xb, 25)
+        P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27) P2T_W4_PAIR(F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_PAIR(F, wb, xb, 31)
+#undef P2T_W4_PAIR
+#undef P2T_W4_R1W
+#undef P2T_W4_R1X
+#undef P2T_W4_R0W
+#undef P2T_W4_R0X
+#undef P2T_W4_G
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the next stage's first fragments are in registers
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 
+    // ring fill (stages 0 and 1 of the job a_ptr / w_ptr point at) + the first fragments
+    auto prologue = [&]() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < ns) {
+    for (int b = 0; b < 2; ++b) {
 #pragma unroll
-            for (int q = 0; q < NL; ++q) dma(q, s, s * 32);
+        for (int q = 0; q < NL; ++q) dma1(q, b);
+        a_ptr += 128; w_ptr += 128;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+    rd(wa[0], w_addr, std::integral_constant<int, 0>{}); rd(wa[1], w_addr, std::integral_constant<int, 2048>{});
+    rd(wa[2], w_addr, std::integral_constant<int, 4096>{}); rd(wa[3], w_addr, std::integral_constant<int, 6144>{});
+    rd(wa[4], w_addr, std::integral_constant<int, 8192>{}); rd(wa[5], w_addr, std::integral_constant<int, 10240>{});
+    rd(wa[6], w_addr, std::integral_constant<int, 12288>{}); rd(wa[7], w_addr, std::integral_constant<int, 14336>{});
+    rd(xa[0], x_addr, std::integral_constant<int, 0>{}); rd(xa[1], x_addr, std::integral_constant<int, 2048>{});
+    rd(xa[2], x_addr, std::integral_constant<int, 4096>{}); rd(xa[3], x_addr, std::integral_constant<int, 6144>{});
+    rd(xa[4], x_addr, std::integral_constant<int, 8192>{}); rd(xa[5], x_addr, std::integral_constant<int, 10240>{});
+    rd(xa[6], x_addr, std::integral_constant<int, 12288>{}); rd(xa[7], x_addr, std::integral_constant<int, 14336>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // Whole tiles: items blockIdx.x, + gridDim.x, ... < n_items.
+    auto k_loop = [&](f32x4 (&acc)[2][4][MT], int nk_l, bool ext, bool has_next, int64_t nm0, int nn0) {
+        stage(acc, I0{}, T{}, F{}, ext, true);
+        stage(acc, I1{}, F{}, F{}, false, true);
+        for (int s = 2; s + 2 < nk_l; s += 2) {        // nk_l is even
+            stage(acc, I0{}, F{}, F{}, false, true);
+            stage(acc, I1{}, F{}, F{}, false, true);
         }
+        if (has_next) {                                 // the last two stages issue the next tile's first two
+            a_ptr = (const char*)(A + nm0 * lda);
+            w_ptr = (const char*)(W + (int64_t)nn0 * ldw);
+        }
+        stage(acc, I0{}, F{}, T{}, false, has_next);
+        stage(acc, I1{}, F{}, T{}, false, has_next);   // (without a next tile its fragment reads fetch stale LDS: unused)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs retire before the epilogue reads accumulators (no hazard tracking across inline asm)
+    };
+    prologue();
     {
-        const int inflight = ns - 1 < 3 ? ns - 1 : 3;
-        if (inflight >= 3) __builtin_amdgcn_s_waitcnt(w4_vm_imm(3 * NL));
-        else if (inflight == 2) __builtin_amdgcn_s_waitcnt(w4_vm_imm(2 * NL));
-        else if (inflight == 1) __builtin_amdgcn_s_waitcnt(w4_vm_imm(NL));
-        else __builtin_amdgcn_s_waitcnt(w4_vm_imm(0));
+        f32x4 acc[2][4][MT];            // [64-column group of the wave][W fragment][activation fragment]
+        bool ext = false;
+        for (;;) {
+            const int nxt = item + (int)gridDim.x;
+            const bool has_next = PERSIST && nxt < n_items;
+            int64_t nm0 = 0;
+            int nn0 = 0;
+            if (has_next) {
+                tile_coords(nxt, n_order, tiles_m, tiles_n, tm, tn);
+                nm0 = (int64_t)tm * 256;
+                nn0 = tn * 256;
+            }
+            k_loop(acc, nk, ext, has_next, nm0, nn0);
+            if (PERSIST) {
+                // launder the lane coordinates so the per-row output addresses are rebuilt per tile instead of being held across the K loop
+                int fr_e = fr, kg_e = kg;
+                asm volatile("" : "+v"(fr_e), "+v"(kg_e));
+                tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr_e, kg_e);
+                tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr_e, kg_e);
+            } else {
+                const bool interior = m0 + 256 <= M && n0 + 256 <= N && n0 + 256 <= n_cover;
+                if (interior) {
+                    tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr, kg);
+                    tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr, kg);
+                } else {
+                    tile_epilogue<MT, Epi, false>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr, kg);
+                    tile_epilogue<MT, Epi, false>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr, kg);
+                }
+            }
+            if (!has_next) break;
+            ext = true;                                 // every wave issued at least kEpiOps operations in that epilogue
+            item = nxt;
+            m0 = nm0;
+            n0 = nn0;
+        }
     }
-    __builtin_amdgcn_s_barrier();
+    // The partial last round: blocks [0, 2 n_tail) take one half of tile n_items + t each -- the SECOND K half as producer
+    // (blocks [0, n_tail): publishes the raw accumulators, never waits) or the FIRST K half as consumer (blocks [n_tail,
+    // 2 n_tail): adds the partner's slab on the way into the epilogue).  Every block of the grid is resident (one per CU), so a
+    // consumer's partner is always running.  Own accumulator variables: the tile loop's register allocation is untouched.
+    if (PERSIST && (int)blockIdx.x < 2 * n_tail) {
+        const bool producer = (int)blockIdx.x < n_tail;
+        const int t = producer ? (int)blockIdx.x : (int)blockIdx.x - n_tail;
+        const int nk0 = (nk >> 1) & ~1;                 // consumer: stages [0, nk0), producer: [nk0, nk)
+        tile_coords(n_items + t, n_order, tiles_m, tiles_n, tm, tn);
+        m0 = (int64_t)tm * 256;
+        n0 = tn * 256;
+        a_ptr = (const char*)(A + m0 * lda + (producer ? nk0 * 64 : 0));
+        w_ptr = (const char*)(W + (int64_t)n0 * ldw + (producer ? nk0 * 64 : 0));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the ring is idle in every wave
+        prologue();
+        f32x4 acc2[2][4][MT];
+        k_loop(acc2, producer ? nk - nk0 : nk0, false, false, 0, 0);
+        if (producer) {
+            // register order: quad q = (h * 4 + i) * MT + j of thread t at slab[q * 256 + t]; drain, then release at agent scope
+            float4* slab = reinterpret_cast<float4*>(fix.slab) + (int64_t)t * (64 * 256) + threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + w_off + i * 1024);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) xa[j] = *reinterpret_cast<const bf16x8*>(smem + x_off + j * 1024);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    int s = 0;
-    for (; s + 5 < ns; s += 2) {
-        step(std::true_type{}, s, xa, wa, xb, wb);
-        step(std::true_type{}, s + 1, xb, wb, xa, wa);
-    }
-    for (; s < ns; s += 2) {                                            // K % 64 == 0: an even number of stages
-        step(std::false_type{}, s, xa, wa, xb, wb);
-        step(std::false_type{}, s + 1, xb, wb, xa, wa);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const bool interior = m0 + 256 <= M && n0 + 256 <= N && n0 + 256 <= n_cover;
-    if (interior) {
-        tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr, kg);
-        tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr, kg);
-    } else {
-        tile_epilogue<MT, Epi, false>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr, kg);
-        tile_epilogue<MT, Epi, false>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr, kg);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        slab[((h * 4 + i) * MT + j) * 256] = make_float4(acc2[h][i][j][0], acc2[h][i][j][1], acc2[h][i][j][2], acc2[h][i][j][3]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(fix.flag + t, fix.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            // wait for the partner (bounded spin; giving up is LOUD: sticky time-out word + NaN tiles, see gemm_mfma.hip)
+            if (threadIdx.x == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(fix.flag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fix.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22)) {
+                        __hip_atomic_store(fix.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            // keep the accumulators where the K loop left them (AGPRs) across the wait: without this the compiler copies all 256
+            // to VGPRs before the spin loop and spills what does not fit
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) asm volatile("" : "+a"(acc2[h][i][j]));
+            const bool timed_out = __hip_atomic_load(fix.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            const float poison = timed_out ? __builtin_nanf("") : 0.f;
+            const float4* slab = reinterpret_cast<const float4*>(fix.slab) + (int64_t)t * (64 * 256) + threadIdx.x;
+            tile_epilogue<MT, Epi, true, true>(acc2[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr, kg, slab, 256, poison);
+            tile_epilogue<MT, Epi, true, true>(acc2[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr, kg, slab + 4 * MT * 256, 256, poison);
+        }
     }
 }
 
@@ -154,16 +288,34 @@ template <typename Epi>
 static int launch_w4(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, const EpiParams& ep,
                      hipStream_t s) {
     const int tiles_m = (int)ceil_div(M, 256), tiles_n = (int)ceil_div(n_cover, 256);
-    gemm_nt_w4_kernel<Epi><<<dim3((unsigned)(tiles_m * tiles_n)), 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tiles_m,
-                                                                              tiles_n, n_cover, ep);
+    gemm_nt_w4_kernel<Epi, false><<<dim3((unsigned)(tiles_m * tiles_n)), 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tiles_m,
+                                                                                     tiles_n, tiles_m * tiles_n, 0, n_cover, ep, SplitFix{});
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }
 
+// Persistent form: n_items whole tiles + n_tail tiles (the partial last round, n_tail <= grid / 2) as split-K pairs, `fix` the
+// hand-off workspace (unused when n_tail == 0).  Caller guarantees: M % 256 == 0, N % 256 == 0 == n_cover, K % 128 == 0,
+// K >= 256 (K >= 1024 with a tail), n_items >= grid when there is a tail.
+template <typename Epi>
+int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
+                           const EpiParams& ep, const SplitFix& fix, hipStream_t s) {
+    gemm_nt_w4_kernel<Epi, true><<<dim3((unsigned)(grid < n_items ? grid : n_items)), 256, 0, s>>>(
+        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+template int launch_gemm_w4_persist<EpiStore<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_persist<EpiStore<float>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_persist<EpiResid>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_persist<EpiQkvRope<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_persist<EpiGelu<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_persist<EpiSwiglu<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+
 // Four-wave form for the epilogues it is built for; P2T_ERR_UNSUPPORTED otherwise (the caller falls back to gemm_mfma.hip).
 int launch_gemm_w4(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int out_dtype, int epilogue,
                    const EpiParams& ep, hipStream_t s) {
-    if (K % 64 != 0 || M < 1 || (int64_t)256 * (lda > ldw ? lda : ldw) * 2 >= (int64_t)1 << 32) return P2T_ERR_UNSUPPORTED;
+    if (K % 128 != 0 || K < 256 || M < 1 || (int64_t)256 * (lda > ldw ? lda : ldw) * 2 >= (int64_t)1 << 32) return P2T_ERR_UNSUPPORTED;
     const bool ob = out_dtype == P2T_BF16;
     switch (epilogue) {
         case P2T_EPI_STORE: return ob ? launch_w4<EpiStore<bf16_t>>(A, lda, W, ldw, M, N, K, n_cover, ep, s) : launch_w4<EpiStore<float>>(A, lda, W, ldw, M, N, K, n_cover, ep, s);

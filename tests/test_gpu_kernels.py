@@ -199,7 +199,7 @@ def test_qkv_rope_epilogue_vs_reference_arithmetic(ops, case, path):
 def test_gemm_argument_errors(ops):
     from p2t_hip import _lib
     with pytest.raises(ValueError):
-        _lib.call("p2t_set_gemm_policy", 7)
+        _lib.call("p2t_set_gemm_policy", 11)
     a, w = torch.zeros((8, 64), device=dev()), torch.zeros((24, 64), device=dev())
     with pytest.raises(ValueError):
         ops.gemm_nt(a, w)                                   # N % 16 != 0
@@ -436,7 +436,7 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, gemm_policy):
     assert rel(got[:, :N], plain[:, :N]) < (1e-6 if epi == EPI_RESID else 2e-3)
 
 
-@pytest.mark.parametrize("tile", ["0", "3", "4", "5", "6"])
+@pytest.mark.parametrize("tile", ["0", "3", "4", "5", "6", "7", "8", "9", "10"])
 def test_gemm_persistent_forms_fuzz(ops, tile, gemm_policy):
     """Random whole-tile shapes through the persistent kernel (default policy / split-K fix-up forced / no fix-up /
     128-row halves for the partial round) against
@@ -464,6 +464,26 @@ def test_gemm_persistent_forms_fuzz(ops, tile, gemm_policy):
             err = float((got[:, :N] - ref[:, :N]).abs().max() / ref[:, :N].abs().max())
             assert err < 2e-5, (M, N, K, epi, err)
     assert int(ws[1024:1028].view(torch.int32).item()) == 0                     # no split-K consumer timed out
+
+
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_GELU, EPI_RESID])
+@pytest.mark.parametrize("shape", [(300, 320, 128), (1000, 96, 256), (513, 1184, 384), (256, 256, 1024), (700, 2560, 2560)])
+def test_gemm_four_wave_form_edges(ops, epi, shape, gemm_policy):
+    """gemm_w4.hip (policy 7) on shapes with edge tiles in M and N and 4 .. 80 stages, against the exact fp32-FMA kernel."""
+    M, N, K = shape
+    a = to_dev(bf16r(rnd(61, "w4.a", (M, K), 1.0)), torch.bfloat16)
+    w = to_dev(bf16r(rnd(61, "w4.w", (N, K), 0.5)), torch.bfloat16)
+    b = to_dev(rnd(61, "w4.b", (N,), 0.3))
+    outs = []
+    for mf in (1, 0):
+        gemm_policy(7 if mf else 0)
+        out = torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None
+        outs.append(ops.gemm_nt(a, w, b, epilogue=epi, out=out, out_dtype=torch.float32 if epi != EPI_GELU else torch.bfloat16, use_mfma=mf))
+    got, ref = outs[0][:, :N].float(), outs[1][:, :N].float()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < (1e-2 if epi == EPI_GELU else 2e-5), (shape, epi, err)
+    if outs[0].shape[1] > N:
+        assert not bool(outs[0][:, N:].any())
 
 
 def test_attention_fuzz_mfma_vs_simple(ops):

@@ -50,13 +50,13 @@ def bench_gemm():
             ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1, fix_ws=ws, fix_epoch=ep[0])
         res = []
         for env, fn in (("2", lambda: ops.gemm_nt(a, w, bias, epilogue=epi, out=out, use_mfma=1)), ("2", with_tail),
-                        ("4", with_tail), ("3", with_tail), (None, with_tail)):
+                        ("4", with_tail), ("3", with_tail), (None, with_tail), ("7", with_tail), ("8", with_tail)):
             _lib.call("p2t_set_gemm_policy", int(env or 0))
             res.append(timeit(fn))
         _lib.call("p2t_set_gemm_policy", 0)
         fl = 2.0 * M * N * K / 1e9
         print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: TF/s per-tile {fl / res[0]:7.1f} | per-tile+splitK {fl / res[1]:7.1f} | "
-              f"persistent {fl / res[2]:7.1f} | persistent+splitK {fl / res[3]:7.1f} | default {fl / res[4]:7.1f} ({res[4]:.3f} ms)", flush=True)
+              f"persistent {fl / res[2]:7.1f} | persistent+splitK {fl / res[3]:7.1f} | default {fl / res[4]:7.1f} ({res[4]:.3f} ms) | four-wave per-tile {fl / res[5]:7.1f} | four-wave persistent {fl / res[6]:7.1f}", flush=True)
 
 
 def bench_cold():
@@ -72,7 +72,7 @@ def bench_cold():
         ws, ep = ops.gemm_fix_workspace(dev), [0]
         fl = 2.0 * M * N * K / 1e9
         res = []
-        for env in ("2", "4", "3", "5", None, "6"):
+        for env in ("2", "4", "3", "5", "9", "7", "8", "10"):
             _lib.call("p2t_set_gemm_policy", int(env or 0))
             tot = 0.0
             for i in range(6):
@@ -89,7 +89,8 @@ def bench_cold():
         _lib.call("p2t_set_gemm_policy", 0)
         print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
               f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | persistent+half-tiles {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f} | "
-              f"default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f} | k64 skeleton {res[5] * 1e3:7.1f} us {fl / res[5]:7.1f}", flush=True)
+              f"eight-wave default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f} | four-wave per-tile {res[5] * 1e3:7.1f} us {fl / res[5]:7.1f} | four-wave persistent + split-K tail {res[6] * 1e3:7.1f} us {fl / res[6]:7.1f} | "
+              f"four-wave persistent, whole tiles only {res[7] * 1e3:7.1f} us {fl / res[7]:7.1f}", flush=True)
 
 
 def bench_ksweep():
