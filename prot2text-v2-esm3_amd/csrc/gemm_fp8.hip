@@ -7,12 +7,12 @@
 //   operand registers 0..3 of lane (r = lane & 15, g = lane >> 4) hold K bytes 16 g .. 16 g + 15 of row r, registers 4..7
 //   hold K bytes 64 + 16 g .. 64 + 16 g + 15 -- two K = 64 halves, each laid out exactly like the bf16 16x16x32 operand
 //   (16 bytes per lane, lane group g = k chunk g); the scale byte of lane 16 b + r applies to (row r, K block b of 32).
-// So the LDS image, the LDS-DMA staging, the source-side bank swizzle and the W-row permutation of the bf16 kernel
-// (gemm_mfma.hip) carry over byte for byte: a "stage" is (BM + 256) rows x 64 bytes = 64 K elements, and one K step of
-// 128 consumes two stages (low / high half of the operand registers).  What differs is the register budget: an operand
+// So the staging scheme of the bf16 kernels carries over (LDS DMA, source-side bank swizzle, W-row permutation): the LDS image
+// of a K step is (BM + 256) rows x 128 bytes (whole cache lines per DMA instruction, as in gemm_w4.hip), the low / high half of
+// the operand registers are the two 64-byte halves of a row.  What differs is the register budget: an operand
 // fragment is 8 registers, so 8 + 4 fragments (96) + 128 accumulators leave no room for double buffering; fragments are
 // reloaded in place as soon as their last MFMA of the step has issued (W fragment i after row i of the 4 x 8 MFMA grid,
-// activation fragment j after MFMA (3, j)) from the OTHER pair of ring slots, and the ring is two K steps deep:
+// activation fragment j after MFMA (3, j)) from the OTHER ring slot, and the ring is two K steps deep:
 //   top of step s:  wait own DMAs (step s+1) + own LDS reads, barrier  ->  DMA of step s+2 into the slots of step s,
 //   interleaved with the 32 MFMAs of step s and the 24 fragment reads of step s+1.
 // Per-tile launch form (one block per tile, XCD-aware grouped tile order), epilogues shared with the bf16 kernel.
@@ -57,10 +57,10 @@ __global__ void __launch_bounds__(512)
                        int64_t ldw, const uint8_t* __restrict__ w_scale, int64_t M, int N, int K, int tiles_m, int tiles_n, int n_cover,
                        EpiParams ep) {
     constexpr int WN = 4, NT = 4, BM = 2 * MT * 16;
-    constexpr int AI = BM / 128;                            // activation DMA pieces per wave per stage (1 KiB each)
-    constexpr int SLOT = (BM + 256) * 64;                   // bytes per stage (64 K bytes of every row)
-    constexpr int NP = 2 * (AI + 2);                        // DMA pieces per wave per K step
-    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+    constexpr int AI = BM / 64;                             // activation DMA pieces per wave per K step (1 KiB each)
+    constexpr int SLOT = (BM + 256) * 128;                  // bytes per K step (128 K bytes of every row)
+    constexpr int NP = AI + 4;                              // DMA pieces per wave per K step
+    __shared__ __attribute__((aligned(16))) char smem[2 * SLOT];
 
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
@@ -72,34 +72,35 @@ __global__ void __launch_bounds__(512)
     const int wm = w / WN, wn = w % WN;
     const int ns = K >> 7;                                  // K steps of 128
 
-    // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row = lane >> 2, 16-byte chunk = lane & 3, swizzled) ----
-    const int schunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
-    const char* a_base = (const char*)A + m0 * lda;         // uniform: tile origin; lane offsets below are the same for every stage
+    // ---- staging: one wave instruction = 8 rows x 128 B -- WHOLE cache lines (half lines, 16 rows x 64 B, cost the loop a
+    // second L2 request for every line: the loop is bound by this path, profiles/r02_microbench_fp8abl.log); lane -> (row =
+    // lane >> 3, 16-byte chunk = lane & 7).  LDS image: 128-byte rows, chunk c of row r at chunk c ^ ((r >> 1) & 7)
+    // (conflict-free fragment reads); the image is lane-linear, so the swizzle is applied to the SOURCE address. ----
+    const char* a_base = (const char*)A + m0 * lda;         // uniform: tile origin; lane offsets below are the same for every step
     const char* w_base = (const char*)W + (int64_t)n0 * ldw;
-    uint32_t a_voff[AI], w_voff[2];
+    uint32_t a_voff[AI], w_voff[4];
 #pragma unroll
     for (int t = 0; t < AI; ++t) {
-        int64_t am = m0 + (w * AI + t) * 16 + (lane >> 2);
+        const int R = (w * AI + t) * 8 + (lane >> 3);
+        int64_t am = m0 + R;
         am = (am < M ? am : M - 1) - m0;                    // rows past the edge re-read the last row (results discarded)
-        a_voff[t] = (uint32_t)(am * lda + schunk * 16);
+        a_voff[t] = (uint32_t)(am * lda + (((lane & 7) ^ ((R >> 1) & 7)) << 4));
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int R = (w * 2 + t) * 16 + (lane >> 2), r = R & 63;
+    for (int t = 0; t < 4; ++t) {
+        const int R = (w * 4 + t) * 8 + (lane >> 3), r = R & 63;
         const int nl = ((r >> 5) & 1) * 32 + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);     // permuted weight row
         int wr = n0 + (R & ~63) + nl;
         wr = (wr < N ? wr : N - 1) - n0;
-        w_voff[t] = (uint32_t)((int64_t)wr * ldw + schunk * 16);
+        w_voff[t] = (uint32_t)((int64_t)wr * ldw + (((lane & 7) ^ ((R >> 1) & 7)) << 4));
     }
     // LDS DMA as inline asm in the saddr form (see gemm_mfma.hip: the builtin makes LLVM drain every counted wait)
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto piece = [&](auto which, int s) {                   // DMA piece `which` (0 .. NP-1) of K step s
-        constexpr int P = decltype(which)::value;
-        constexpr int H = P / (AI + 2), Q = P % (AI + 2);   // stage half, piece within the stage: Q < AI activation, else weight
-        const int stage = 2 * s + H;
-        const char* sb = (Q < AI ? a_base : w_base) + (int64_t)stage * 64;
+    auto piece = [&](auto which, int s) {                   // DMA piece `which` (0 .. NP-1) of K step s: Q < AI activation, else weight
+        constexpr int Q = decltype(which)::value;
+        const char* sb = (Q < AI ? a_base : w_base) + (int64_t)s * 128;
         const uint32_t vo = Q < AI ? a_voff[Q < AI ? Q : 0] : w_voff[Q < AI ? 0 : Q - AI];
-        const uint32_t lds = lds0 + (stage & 3) * SLOT + (Q < AI ? (w * AI + Q) * 1024 : BM * 64 + (w * 2 + (Q - AI)) * 1024);
+        const uint32_t lds = lds0 + (s & 1) * SLOT + (Q < AI ? (w * AI + Q) * 1024 : BM * 128 + (w * 4 + (Q - AI)) * 1024);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(lds) : "memory");
     };
     auto issue_all = [&](int s) {
@@ -109,14 +110,15 @@ __global__ void __launch_bounds__(512)
         if constexpr (NP == 8) { piece(std::integral_constant<int, 6>{}, s); piece(std::integral_constant<int, 7>{}, s); }
     };
 
-    // ---- fragment read offsets (as the bf16 kernel) ----
+    // ---- fragment read offsets: K bytes 16 g .. of row fr (low registers) and 64 + 16 g .. (high registers) ----
     const int fr = lane & 15, kg = lane >> 4;
-    const int sw = (kg ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4;
-    const int x_off = (wm * MT * 16 + fr) * 64 + sw;
-    const int w_off = BM * 64 + (wn * NT * 16 + fr) * 64 + sw;
-    auto frag = [&](int s, int off) -> v8i {                // low half from stage 2 s, high half from stage 2 s + 1
-        const v4i lo = *reinterpret_cast<const v4i*>(smem + ((2 * s) & 3) * SLOT + off);
-        const v4i hi = *reinterpret_cast<const v4i*>(smem + ((2 * s + 1) & 3) * SLOT + off);
+    const int sw = (kg ^ ((fr >> 1) & 7)) << 4;
+    const int x_off = (wm * MT * 16 + fr) * 128 + sw;
+    const int w_off = BM * 128 + (wn * NT * 16 + fr) * 128 + sw;
+    constexpr int FS = 2048;                                // bytes between consecutive fragments (16 rows)
+    auto frag = [&](int s, int off) -> v8i {
+        const v4i lo = *reinterpret_cast<const v4i*>(smem + (s & 1) * SLOT + off);
+        const v4i hi = *reinterpret_cast<const v4i*>(smem + (s & 1) * SLOT + (off ^ 64));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
@@ -149,9 +151,9 @@ __global__ void __launch_bounds__(512)
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     v8i X[MT], Wf[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) Wf[i] = frag(0, w_off + i * 1024);
+    for (int i = 0; i < NT; ++i) Wf[i] = frag(0, w_off + i * FS);
 #pragma unroll
-    for (int j = 0; j < MT; ++j) X[j] = frag(0, x_off + j * 1024);
+    for (int j = 0; j < MT; ++j) X[j] = frag(0, x_off + j * FS);
 
     // One K step.  MORE: a step s + 1 exists (reload the fragments); ISSUE: a step s + 2 exists (start its DMA).  Both are
     // compile-time so the steady-state body is branch-free; the last two steps are peeled below.
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(512)
             auto reloadx = [&](auto jj) {
                 constexpr int J = decltype(jj)::value;
                 if constexpr (MORE && I == NT - 1) {        // last use of the activation fragments J, J + 1 was just issued
-                    X[J] = frag(s + 1, x_off + J * 1024);
-                    X[J + 1] = frag(s + 1, x_off + (J + 1) * 1024);
+                    X[J] = frag(s + 1, x_off + J * FS);
+                    X[J + 1] = frag(s + 1, x_off + (J + 1) * FS);
                 }
             };
             // DMA of step s + 2 as EARLY in the step as the issue slots allow (rows 0 and 1, one piece per MFMA pair): its data
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(512)
                 reloadx(std::integral_constant<int, 6>{});
             }
             if constexpr (MT < 8 && I < 2) dma2(std::integral_constant<int, 4 + I>{});   // 128-row tiles: 6 pieces, 3 per row
-            if constexpr (MORE) Wf[I] = frag(s + 1, w_off + I * 1024);   // row I done: its W fragment is free
+            if constexpr (MORE) Wf[I] = frag(s + 1, w_off + I * FS);   // row I done: its W fragment is free
             __builtin_amdgcn_sched_barrier(0);
         };
         row(std::integral_constant<int, 0>{});
