@@ -67,9 +67,10 @@ __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
 __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {       // one v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef float p2t_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 p2t_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(p2t_f32x2{lo, hi}, p2t_bf16x2));
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));

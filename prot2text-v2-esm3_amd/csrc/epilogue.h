@@ -294,7 +294,10 @@ struct EpiQkvRope {
         const int blk = n >> 6;
         const int head = hd == 64 ? blk : blk >> 1;
         const int j = (hd == 64 ? 0 : 32 * (blk & 1)) + (n & 31);          // rotary channel: pairs (j, j + hd/2)
-        const int b = (int)(m / p.seq), t = (int)(m - (int64_t)b * p.seq);
+        // 32-bit unsigned arithmetic (gemm_nt checks M < 2^31 and B * heads * seq < 2^31): a 64-bit division per row was a
+        // third of this epilogue's instructions
+        const uint32_t mu = (uint32_t)m, sq = (uint32_t)p.seq;
+        const uint32_t b = mu / sq, t = mu - b * sq;
         float x1[W], x2[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) { x1[e] = v0[e] + b0[e]; x2[e] = v1[e] + b1[e]; }
@@ -303,20 +306,20 @@ struct EpiQkvRope {
             const bool is_q = head < p.nh;
             const float sc = is_q ? p.q_scale : 1.0f;
             float c[W], s[W], o1[W], o2[W];
-            loadW<W>(p.cs + (int64_t)t * hd + j, c);
-            loadW<W>(p.cs + (int64_t)t * hd + half + j, s);
+            loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + j, c);
+            loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + half + j, s);
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 const float a1 = x1[e] * sc, a2 = x2[e] * sc;
                 o1[e] = a1 * c[e] - a2 * s[e];
                 o2[e] = a2 * c[e] + a1 * s[e];
             }
-            dst = is_q ? (Tout*)p.q + (((int64_t)b * p.nh + head) * p.seq + t) * hd
-                       : (Tout*)p.k + (((int64_t)b * p.nkv + (head - p.nh)) * p.seq + t) * hd;
+            dst = is_q ? (Tout*)p.q + (size_t)((b * (uint32_t)p.nh + (uint32_t)head) * sq + t) * (size_t)hd
+                       : (Tout*)p.k + (size_t)((b * (uint32_t)p.nkv + (uint32_t)(head - p.nh)) * sq + t) * (size_t)hd;
             storeW<W>(dst + j, o1);
             storeW<W>(dst + half + j, o2);
         } else {
-            dst = (Tout*)p.v + (((int64_t)b * p.nkv + (head - p.nh - p.nkv)) * p.seq + t) * hd;
+            dst = (Tout*)p.v + (size_t)((b * (uint32_t)p.nkv + (uint32_t)(head - p.nh - p.nkv)) * sq + t) * (size_t)hd;
             storeW<W>(dst + j, x1);
             storeW<W>(dst + half + j, x2);
         }

@@ -56,6 +56,8 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
     P2T_REQUIRE(!rope || (a.cs && a.q && a.k && a.v && a.seq > 0 && (a.head_dim == 64 || a.head_dim == 128) &&
                           a.N == (int64_t)(a.nh + 2 * a.nkv) * a.head_dim && a.M % a.seq == 0),
                 "gemm_nt: EPI_QKV_ROPE needs head_dim 64 or 128 outputs, the rotary table and M = B * seq");
+    P2T_REQUIRE(!rope || (a.M < ((int64_t)1 << 31) && a.M * (int64_t)(a.nh > a.nkv ? a.nh : a.nkv) < ((int64_t)1 << 31)),
+                "gemm_nt: EPI_QKV_ROPE indexes rows of the head-split outputs in 32 bits (M * heads = %lld)", (long long)(a.M * (a.nh > a.nkv ? a.nh : a.nkv)));
     if (a.dtype == P2T_FP8)
         P2T_REQUIRE(a.a_scale && a.w_scale && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && (uintptr_t)a.A % 16 == 0 &&
                         (uintptr_t)a.W % 16 == 0 && a.epilogue != P2T_EPI_GELU_BWD && (a.epilogue != P2T_EPI_GELU_FP8 || a.out_row_scale),
