@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(256)
                       int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix) {
     constexpr int MT = 8, NT = 8, BUF = 512 * 128, WOFF = 256 * 128, NL = 16;
     constexpr int kEpiOps = 2 * MT * Epi::kMinOps;
-    constexpr int kExtCount = NL + kEpiOps > 63 ? 63 : NL + kEpiOps;
+    constexpr int kIssuedBeforeWait = 6;    // DMA pieces of stage s+2 a wave has issued when it waits for stage s+1 (tools/gen_w4_schedule.py)
+    constexpr int kExtCount = kIssuedBeforeWait + kEpiOps > 63 ? 63 : kIssuedBeforeWait + kEpiOps;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63;
@@ -114,26 +115,32 @@ __global__ void __launch_bounds__(256)
 #define P2T_W4_R0W(I) rd(wa[I], ws0, std::integral_constant<int, (I) * 2048>{});
 #define P2T_W4_R0X(J) rd(xa[J], xs0, std::integral_constant<int, (J) * 2048>{});
 #define P2T_W4_G(Q) if (!RT || more) dma1(Q, B);
+#define P2T_W4_WAIT_NEXT_STAGE                                                                                                  \
+        if (RT && !more) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+        else if (FI::value && ext) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kExtCount) : "memory");                 \
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kIssuedBeforeWait) : "memory");
+        // GENERATED (tools/gen_w4_schedule.py) BEGIN -- DMA pieces issued before the second-half wait: 6
         P2T_W4_R1W(0) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1X(0) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 3)
         P2T_W4_R1W(3) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1W(4) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 7)
         P2T_W4_R1X(2) P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_R1W(7) P2T_W4_PAIR(FI, wa, xa, 10) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 11)
         P2T_W4_R1X(4) P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_R1X(6) P2T_W4_PAIR(FI, wa, xa, 14) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 15)
         P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_PAIR(FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        P2T_W4_G(0) P2T_W4_PAIR(FI, wa, xa, 20) P2T_W4_G(1) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_G(2) P2T_W4_PAIR(FI, wa, xa, 22) P2T_W4_G(3) P2T_W4_PAIR(FI, wa, xa, 23)
-        P2T_W4_G(4) P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_G(5) P2T_W4_PAIR(FI, wa, xa, 25) P2T_W4_G(6) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_G(7) P2T_W4_PAIR(FI, wa, xa, 27)
-        P2T_W4_G(8) P2T_W4_PAIR(FI, wa, xa, 28) P2T_W4_G(9) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_G(10) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_G(11) P2T_W4_PAIR(FI, wa, xa, 31)
-        P2T_W4_G(12) P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_G(13) P2T_W4_PAIR(F, wb, xb, 1) P2T_W4_G(14) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_G(15) P2T_W4_PAIR(F, wb, xb, 3)
+        P2T_W4_G(0) P2T_W4_PAIR(FI, wa, xa, 20) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_G(1) P2T_W4_PAIR(FI, wa, xa, 22) P2T_W4_PAIR(FI, wa, xa, 23)
+        P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_G(2) P2T_W4_PAIR(FI, wa, xa, 25) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_PAIR(FI, wa, xa, 27)
+        P2T_W4_G(3) P2T_W4_PAIR(FI, wa, xa, 28) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_G(4) P2T_W4_PAIR(FI, wa, xa, 31)
+        P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_G(5) P2T_W4_PAIR(F, wb, xb, 1) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_PAIR(F, wb, xb, 3)
+        P2T_W4_WAIT_NEXT_STAGE
+        P2T_W4_R0W(0) P2T_W4_G(6) P2T_W4_PAIR(F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_G(7) P2T_W4_PAIR(F, wb, xb, 7)
+        P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_G(8) P2T_W4_PAIR(F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
+        P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_G(9) P2T_W4_PAIR(F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
+        P2T_W4_R0X(4) P2T_W4_G(10) P2T_W4_PAIR(F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_G(11) P2T_W4_PAIR(F, wb, xb, 19)
+        P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_G(12) P2T_W4_PAIR(F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23)
+        P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_G(13) P2T_W4_PAIR(F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
+        P2T_W4_G(14) P2T_W4_PAIR(F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_G(15) P2T_W4_PAIR(F, wb, xb, 31)
+        // GENERATED END
         a_ptr += 128; w_ptr += 128;
-        if (RT && !more) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (FI::value && ext) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kExtCount) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
-        P2T_W4_R0W(0) P2T_W4_PAIR(F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_PAIR(F, wb, xb, 7)
-        P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_PAIR(F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
-        P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_PAIR(F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
-        P2T_W4_R0X(4) P2T_W4_PAIR(F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_PAIR(F, wb, xb, 19)
-        P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_PAIR(F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23) P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_PAIR(F, wb, xb, 25)
-        P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27) P2T_W4_PAIR(F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_PAIR(F, wb, xb, 31)
+#undef P2T_W4_WAIT_NEXT_STAGE
 #undef P2T_W4_PAIR
 #undef P2T_W4_R1W
 #undef P2T_W4_R1X
