@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(512)
                 }
             };
             // DMA of step s + 2 as EARLY in the step as the issue slots allow (rows 0 and 1, one piece per MFMA pair): its data
-            // is waited for at the top of step s + 1, so every cycle it is issued earlier is latency hidden
+            // is waited for at the top of step s + 1, so every cycle it is issued earlier is latency hidden (spreading the pieces
+            // evenly over the four rows, which pays in the one-wave-per-SIMD kernel of gemm_w4.hip, measured -2.8 % here: with two
+            // waves per SIMD the partner covers a queued piece's issue stall)
             constexpr int PPR = MT >= 8 ? 4 : 2;            // pieces per row
             two(std::integral_constant<int, 0>{});
             dma2(std::integral_constant<int, (I < 2 ? PPR * I : NP)>{});
