@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(512)
 // gemm_w4.hip: persistent four-wave form over the first n_items tiles of the order of n_order tiles
 template <typename Epi>
 int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
-                           const EpiParams& ep, const SplitFix& fix, hipStream_t s);
+                           const EpiParams& ep, const SplitFix& fix, hipStream_t s, int sched);
 template <typename Epi>
 constexpr bool kHasW4 = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value || std::is_same<Epi, EpiResid>::value ||
                         std::is_same<Epi, EpiQkvRope<bf16_t>>::value || std::is_same<Epi, EpiGelu<bf16_t>>::value || std::is_same<Epi, EpiSwiglu<bf16_t>>::value;
@@ -556,7 +556,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
         // 0.4 % of the step; with it hot in the Infinity Cache, as in the micro-benchmark, the per-tile kernel is 6 % ahead)
         const int64_t rem = items % kCUs;
         const bool eligible = items >= kCUs && (ns & 3) == 0 && ns >= 12 && M % 256 == 0 && N % 256 == 0 && n_cover == N;
-        const bool pick = tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
+        const bool pick = tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || tile == 12 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
         if (eligible && pick) {
             int64_t n_full = items, n_tail = 0;
             int half_tail = 0;
@@ -581,6 +581,8 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
             if constexpr (kHasW4<Epi>) {
                 // four-wave form (gemm_w4.hip): the tiles of a partial last round run as split-K pairs inside the same
                 // persistent stream (tile == 10: as whole tiles)
+                const int sched = tile == 12 ? 0 : 1;             // 12: the other instruction order of the four-wave K loop (tools/gen_w4_schedule.py)
+                if (tile == 12) tile = 10;
                 const bool w4 = !no_w4 && (tile == 0 || tile == 8 || tile == 10) && (int64_t)256 * (lda > ldw ? lda : ldw) * 2 < ((int64_t)1 << 32) && ns >= 8;
                 if (w4) {
                     SplitFix f4{};
@@ -594,7 +596,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
                         f4.slab = (float*)((char*)fix_ws + kFixHeader);
                         f4.epoch = fix_epoch;
                     }
-                    return launch_gemm_w4_persist<Epi>(A, lda, W, ldw, M, N, K, (int)(items - t4), (int)t4, kCUs, ep, f4, s);
+                    return launch_gemm_w4_persist<Epi>(A, lda, W, ldw, M, N, K, (int)(items - t4), (int)t4, kCUs, ep, f4, s, sched);
                 }
             }
             gemm_nt_mfma_persist_kernel<Epi><<<dim3(kCUs), 512, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K,
@@ -603,7 +605,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
             P2T_LAUNCH_CHECK();
             return P2T_OK;
         }
-        if (tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10) tile = 0;
+        if (tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || tile == 12) tile = 0;
     }
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);

@@ -25,13 +25,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // an epilogue waits with a count that leaves the epilogue's operations in flight (Epi::kMinOps is a lower bound of them: the
 // persistent form only takes shapes without edge tiles, where every wave issues all of them).  Requires M % 256 == 0,
 // N % 256 == 0 == n_cover, K % 128 == 0, K >= 256.  !PERSIST: one tile per block, any M / N (rows clamped, edge epilogue).
-template <typename Epi, bool PERSIST>
+template <typename Epi, bool PERSIST, int SCHED = 0>
 __global__ void __launch_bounds__(256)
     gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M, int N, int K,
                       int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix) {
     constexpr int MT = 8, NT = 8, BUF = 512 * 128, WOFF = 256 * 128, NL = 16;
     constexpr int kEpiOps = 2 * MT * Epi::kMinOps;
-    constexpr int kIssuedBeforeWait = 6;    // DMA pieces of stage s+2 a wave has issued when it waits for stage s+1 (tools/gen_w4_schedule.py)
+    constexpr int kIssuedBeforeWait = SCHED == 0 ? 6 : 9;    // DMA pieces of stage s+2 a wave has issued when it waits for stage s+1 (tools/gen_w4_schedule.py)
     constexpr int kExtCount = kIssuedBeforeWait + kEpiOps > 63 ? 63 : kIssuedBeforeWait + kEpiOps;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
@@ -92,6 +92,17 @@ __global__ void __launch_bounds__(256)
         const uint32_t lds = lds0 + buf * BUF + (piece < 8 ? 0 : WOFF) + (w * 8 + (piece & 7)) * 1024;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(lds) : "memory");
     };
+    auto mm_dma = [&](auto first, f32x4& c, const bf16x8& a, const bf16x8& b, int piece, int buf) {
+        const char* sb = piece < 8 ? a_ptr : w_ptr;
+        const uint32_t vo = piece < 8 ? a_voff[piece & 7] : w_voff[piece & 7];
+        const uint32_t lds = lds0 + buf * BUF + (piece < 8 ? 0 : WOFF) + (w * 8 + (piece & 7)) * 1024;
+        if constexpr (decltype(first)::value)
+            asm volatile("s_mov_b32 m0, %5\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\tglobal_load_lds_dwordx4 %3, %4"
+                         : "=a"(c) : "v"(a), "v"(b), "v"(vo), "s"(sb), "s"(lds) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %5\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tglobal_load_lds_dwordx4 %3, %4"
+                         : "+a"(c) : "v"(a), "v"(b), "v"(vo), "s"(sb), "s"(lds) : "memory");
+    };
     using T = std::true_type;
     using F = std::false_type;
     // One 64-deep stage s (buffer B = s & 1); its K-half-0 fragments are in (xa, wa).
@@ -115,29 +126,60 @@ __global__ void __launch_bounds__(256)
 #define P2T_W4_R0W(I) rd(wa[I], ws0, std::integral_constant<int, (I) * 2048>{});
 #define P2T_W4_R0X(J) rd(xa[J], xs0, std::integral_constant<int, (J) * 2048>{});
 #define P2T_W4_G(Q) if (!RT || more) dma1(Q, B);
+// a pair that carries DMA piece Q: M0 is set before the pair's first MFMA and the DMA goes behind it (the MFMA is the wait
+// state the M0 write needs: no s_nop); stages whose DMA is conditional (RT) keep the separate form
+#define P2T_W4_GPAIR(Q, FF, WF, XF, P)                                                                                           \
+        if constexpr (!RT) {                                                                                                     \
+            mm_dma(FF{}, acc[(((P) & 3) * 2) >> 2][(((P) & 3) * 2) & 3][(P) >> 2], WF[((P) & 3) * 2], XF[(P) >> 2], Q, B);       \
+            mm(FF{}, acc[(((P) & 3) * 2 + 1) >> 2][(((P) & 3) * 2 + 1) & 3][(P) >> 2], WF[((P) & 3) * 2 + 1], XF[(P) >> 2]);     \
+        } else {                                                                                                                 \
+            P2T_W4_G(Q) P2T_W4_PAIR(FF, WF, XF, P)                                                                               \
+        }
 #define P2T_W4_WAIT_NEXT_STAGE                                                                                                  \
         if (RT && !more) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                          \
         else if (FI::value && ext) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kExtCount) : "memory");                 \
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kIssuedBeforeWait) : "memory");
-        // GENERATED (tools/gen_w4_schedule.py) BEGIN -- DMA pieces issued before the second-half wait: 6
-        P2T_W4_R1W(0) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1X(0) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 3)
-        P2T_W4_R1W(3) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1W(4) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 7)
-        P2T_W4_R1X(2) P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_R1W(7) P2T_W4_PAIR(FI, wa, xa, 10) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 11)
-        P2T_W4_R1X(4) P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_R1X(6) P2T_W4_PAIR(FI, wa, xa, 14) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 15)
-        P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_PAIR(FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        P2T_W4_G(0) P2T_W4_PAIR(FI, wa, xa, 20) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_G(1) P2T_W4_PAIR(FI, wa, xa, 22) P2T_W4_PAIR(FI, wa, xa, 23)
-        P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_G(2) P2T_W4_PAIR(FI, wa, xa, 25) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_PAIR(FI, wa, xa, 27)
-        P2T_W4_G(3) P2T_W4_PAIR(FI, wa, xa, 28) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_G(4) P2T_W4_PAIR(FI, wa, xa, 31)
-        P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_G(5) P2T_W4_PAIR(F, wb, xb, 1) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_PAIR(F, wb, xb, 3)
-        P2T_W4_WAIT_NEXT_STAGE
-        P2T_W4_R0W(0) P2T_W4_G(6) P2T_W4_PAIR(F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_G(7) P2T_W4_PAIR(F, wb, xb, 7)
-        P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_G(8) P2T_W4_PAIR(F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
-        P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_G(9) P2T_W4_PAIR(F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
-        P2T_W4_R0X(4) P2T_W4_G(10) P2T_W4_PAIR(F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_G(11) P2T_W4_PAIR(F, wb, xb, 19)
-        P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_G(12) P2T_W4_PAIR(F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23)
-        P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_G(13) P2T_W4_PAIR(F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
-        P2T_W4_G(14) P2T_W4_PAIR(F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_G(15) P2T_W4_PAIR(F, wb, xb, 31)
+        // GENERATED (tools/gen_w4_schedule.py) BEGIN
+        if constexpr (SCHED == 0) {
+            P2T_W4_R1W(0) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1X(0) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 3)
+            P2T_W4_R1W(3) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1W(4) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 7)
+            P2T_W4_R1X(2) P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_R1W(7) P2T_W4_PAIR(FI, wa, xa, 10) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 11)
+            P2T_W4_R1X(4) P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_R1X(6) P2T_W4_PAIR(FI, wa, xa, 14) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 15)
+            P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_PAIR(FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P2T_W4_GPAIR(0, FI, wa, xa, 20) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_GPAIR(1, FI, wa, xa, 22) P2T_W4_PAIR(FI, wa, xa, 23)
+            P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_GPAIR(2, FI, wa, xa, 25) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_PAIR(FI, wa, xa, 27)
+            P2T_W4_GPAIR(3, FI, wa, xa, 28) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_GPAIR(4, FI, wa, xa, 31)
+            P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_GPAIR(5, F, wb, xb, 1) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_PAIR(F, wb, xb, 3)
+            P2T_W4_WAIT_NEXT_STAGE
+            P2T_W4_R0W(0) P2T_W4_GPAIR(6, F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_GPAIR(7, F, wb, xb, 7)
+            P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_GPAIR(8, F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
+            P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_GPAIR(9, F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
+            P2T_W4_R0X(4) P2T_W4_GPAIR(10, F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_GPAIR(11, F, wb, xb, 19)
+            P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_GPAIR(12, F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23)
+            P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_GPAIR(13, F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
+            P2T_W4_GPAIR(14, F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_GPAIR(15, F, wb, xb, 31)
+        } else if constexpr (SCHED == 1) {
+            P2T_W4_R1W(0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1X(0) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1W(3) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(4) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 3)
+            P2T_W4_R1X(2) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1W(7) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1X(4) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1X(6) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 7)
+            P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_PAIR(FI, wa, xa, 10)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P2T_W4_GPAIR(0, FI, wa, xa, 11)
+            P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_GPAIR(1, FI, wa, xa, 14) P2T_W4_PAIR(FI, wa, xa, 15)
+            P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_GPAIR(2, FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
+            P2T_W4_GPAIR(3, FI, wa, xa, 20) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_PAIR(FI, wa, xa, 22) P2T_W4_GPAIR(4, FI, wa, xa, 23)
+            P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_PAIR(FI, wa, xa, 25) P2T_W4_GPAIR(5, FI, wa, xa, 26) P2T_W4_PAIR(FI, wa, xa, 27)
+            P2T_W4_PAIR(FI, wa, xa, 28) P2T_W4_GPAIR(6, FI, wa, xa, 29) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_PAIR(FI, wa, xa, 31)
+            P2T_W4_GPAIR(7, F, wb, xb, 0) P2T_W4_PAIR(F, wb, xb, 1) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_GPAIR(8, F, wb, xb, 3)
+            P2T_W4_WAIT_NEXT_STAGE
+            P2T_W4_R0W(0) P2T_W4_PAIR(F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_GPAIR(9, F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_PAIR(F, wb, xb, 7)
+            P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_GPAIR(10, F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_PAIR(F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
+            P2T_W4_R0X(2) P2T_W4_GPAIR(11, F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_PAIR(F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_GPAIR(12, F, wb, xb, 15)
+            P2T_W4_R0X(4) P2T_W4_PAIR(F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_GPAIR(13, F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_PAIR(F, wb, xb, 19)
+            P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_GPAIR(14, F, wb, xb, 21) P2T_W4_PAIR(F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23)
+            P2T_W4_GPAIR(15, F, wb, xb, 24) P2T_W4_PAIR(F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
+            P2T_W4_PAIR(F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_PAIR(F, wb, xb, 31)
+        }
         // GENERATED END
         a_ptr += 128; w_ptr += 128;
 #undef P2T_W4_WAIT_NEXT_STAGE
@@ -147,6 +189,7 @@ __global__ void __launch_bounds__(256)
 #undef P2T_W4_R0W
 #undef P2T_W4_R0X
 #undef P2T_W4_G
+#undef P2T_W4_GPAIR
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the next stage's first fragments are in registers
     };
     using I0 = std::integral_constant<int, 0>;
@@ -306,18 +349,21 @@ static int launch_w4(const void* A, int64_t lda, const void* W, int64_t ldw, int
 // K >= 256 (K >= 1024 with a tail), n_items >= grid when there is a tail.
 template <typename Epi>
 int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
-                           const EpiParams& ep, const SplitFix& fix, hipStream_t s) {
-    gemm_nt_w4_kernel<Epi, true><<<dim3((unsigned)(grid < n_items ? grid : n_items)), 256, 0, s>>>(
-        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
+                           const EpiParams& ep, const SplitFix& fix, hipStream_t s, int sched) {
+    const dim3 g((unsigned)(grid < n_items ? grid : n_items));
+    if (sched == 1)
+        gemm_nt_w4_kernel<Epi, true, 1><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
+    else
+        gemm_nt_w4_kernel<Epi, true, 0><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }
-template int launch_gemm_w4_persist<EpiStore<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
-template int launch_gemm_w4_persist<EpiStore<float>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
-template int launch_gemm_w4_persist<EpiResid>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
-template int launch_gemm_w4_persist<EpiQkvRope<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
-template int launch_gemm_w4_persist<EpiGelu<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
-template int launch_gemm_w4_persist<EpiSwiglu<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_persist<EpiStore<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
+template int launch_gemm_w4_persist<EpiStore<float>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
+template int launch_gemm_w4_persist<EpiResid>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
+template int launch_gemm_w4_persist<EpiQkvRope<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
+template int launch_gemm_w4_persist<EpiGelu<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
+template int launch_gemm_w4_persist<EpiSwiglu<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
 
 // Four-wave form for the epilogues it is built for; P2T_ERR_UNSUPPORTED otherwise (the caller falls back to gemm_mfma.hip).
 int launch_gemm_w4(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int out_dtype, int epilogue,

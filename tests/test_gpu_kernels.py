@@ -436,7 +436,7 @@ def test_gemm_mfma_splitk_tail(ops, epi, path, shape, gemm_policy):
     assert rel(got[:, :N], plain[:, :N]) < (1e-6 if epi == EPI_RESID else 2e-3)
 
 
-@pytest.mark.parametrize("tile", ["0", "3", "4", "5", "6", "7", "8", "9", "10"])
+@pytest.mark.parametrize("tile", ["0", "3", "4", "5", "6", "7", "8", "9", "10", "12"])
 def test_gemm_persistent_forms_fuzz(ops, tile, gemm_policy):
     """Random whole-tile shapes through the persistent kernel (default policy / split-K fix-up forced / no fix-up /
     128-row halves for the partial round) against

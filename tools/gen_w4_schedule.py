@@ -16,63 +16,85 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc", "gemm_w4.hip")
 
 READ_ORDER = ["W0", "W1", "X0", "W2", "W3", "X1", "W4", "W5", "X2", "W6", "W7", "X3", "X4", "X5", "X6", "X7"]
-DMA_FIRST = [20, 22, 25, 28, 31]                       # pairs of the first half that carry a DMA piece (after the barrier behind pair 19)
-DMA_SECOND = [1, 4, 7, 10, 13, 16, 19, 22, 25, 28, 31]  # pairs of the second half
-WAIT_AFTER_SECOND = 3                                   # vmcnt + barrier behind this pair of the second half
-READS_SECOND_FROM = 4                                   # next-stage K-half-0 reads behind pairs 4 .. 19
+# schedule = (reads per pair in the first half, pair behind which the mid-stage lgkmcnt(0) + barrier sits, DMA pairs of the first
+#             half, DMA pairs of the second half, pair of the second half behind which the vmcnt wait + barrier sits,
+#             first pair of the second half that carries a read, reads per pair there)
+SCHEDULES = {
+    0: dict(rpp1=1, bar1=19, dma1=[20, 22, 25, 28, 31], dma2=[1, 4, 7, 10, 13, 16, 19, 22, 25, 28, 31], wait2=3, rd2=4, rpp2=1),
+    1: dict(rpp1=2, bar1=10, dma1=[11, 14, 17, 20, 23, 26, 29], dma2=[0, 3, 6, 9, 12, 15, 18, 21, 24], wait2=3, rd2=4, rpp2=1),
+}
 
 
-def main():
-    assert len(DMA_FIRST) + len(DMA_SECOND) == 16
-    issued_before_wait = len(DMA_FIRST) + sum(1 for p in DMA_SECOND if p <= WAIT_AFTER_SECOND)
-    out = []
+def emit(sc):
+    out, line = [], []
     q = 0
-    line = []
+    nread = 0
 
     def flush():
         if line:
-            out.append("        " + " ".join(line))
+            out.append("            " + " ".join(line))
             line.clear()
 
+    assert len(sc["dma1"]) + len(sc["dma2"]) == 16 and min(sc["dma1"]) > sc["bar1"]
     for p in range(32):                                 # first half
-        if p < 16:
-            r = READ_ORDER[p]
-            line.append(f"P2T_W4_R1{r[0]}({r[1]})")
-        if p in DMA_FIRST:
-            line.append(f"P2T_W4_G({q})")
+        for _ in range(sc["rpp1"]):
+            if nread < 16:
+                r = READ_ORDER[nread]
+                line.append(f"P2T_W4_R1{r[0]}({r[1]})")
+                nread += 1
+        if p in sc["dma1"]:
+            line.append(f"P2T_W4_GPAIR({q}, FI, wa, xa, {p})")
             q += 1
-        line.append(f"P2T_W4_PAIR(FI, wa, xa, {p})")
+        else:
+            line.append(f"P2T_W4_PAIR(FI, wa, xa, {p})")
         if p % 4 == 3:
             flush()
-        if p == 19:
+        if p == sc["bar1"]:
+            assert nread == 16
             flush()
-            out.append('        asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");')
+            out.append('            asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");')
     flush()
+    nread = 0
     for p in range(32):                                 # second half
-        if READS_SECOND_FROM <= p < READS_SECOND_FROM + 16:
-            r = READ_ORDER[p - READS_SECOND_FROM]
-            line.append(f"P2T_W4_R0{r[0]}({r[1]})")
-        if p in DMA_SECOND:
-            line.append(f"P2T_W4_G({q})")
+        if p >= sc["rd2"]:
+            for _ in range(sc["rpp2"]):
+                if nread < 16:
+                    r = READ_ORDER[nread]
+                    line.append(f"P2T_W4_R0{r[0]}({r[1]})")
+                    nread += 1
+        if p in sc["dma2"]:
+            line.append(f"P2T_W4_GPAIR({q}, F, wb, xb, {p})")
             q += 1
-        line.append(f"P2T_W4_PAIR(F, wb, xb, {p})")
+        else:
+            line.append(f"P2T_W4_PAIR(F, wb, xb, {p})")
         if p % 4 == 3:
             flush()
-        if p == WAIT_AFTER_SECOND:
+        if p == sc["wait2"]:
             flush()
-            out.append("        P2T_W4_WAIT_NEXT_STAGE")
+            out.append("            P2T_W4_WAIT_NEXT_STAGE")
     flush()
-    assert q == 16
-    body = "\n".join(out)
+    assert q == 16 and nread == 16 and sc["rd2"] > sc["wait2"]
+    before = len(sc["dma1"]) + sum(1 for p in sc["dma2"] if p <= sc["wait2"])
+    return "\n".join(out), before
+
+
+def main():
+    parts, counts = [], []
+    for k in sorted(SCHEDULES):
+        body, before = emit(SCHEDULES[k])
+        counts.append(before)
+        parts.append(("        if constexpr (SCHED == %d) {\n" % k if k == 0 else "        } else if constexpr (SCHED == %d) {\n" % k) + body + "\n")
+    text = "".join(parts) + "        }\n"
     with open(PATH) as f:
         s = f.read()
     a = s.index("        // GENERATED (tools/gen_w4_schedule.py) BEGIN")
     b = s.index("        // GENERATED END")
-    s = s[:a] + f"        // GENERATED (tools/gen_w4_schedule.py) BEGIN -- DMA pieces issued before the second-half wait: {issued_before_wait}\n" + body + "\n" + s[b:]
-    s = re.sub(r"constexpr int kIssuedBeforeWait = \d+;", f"constexpr int kIssuedBeforeWait = {issued_before_wait};", s)
+    s = s[:a] + "        // GENERATED (tools/gen_w4_schedule.py) BEGIN\n" + text + s[b:]
+    s = re.sub(r"constexpr int kIssuedBeforeWait = [^;]*;", "constexpr int kIssuedBeforeWait = " + " : ".join(
+        [f"SCHED == {k} ? {c}" for k, c in zip(sorted(SCHEDULES), counts)][:-1] + [str(counts[-1])]) + ";", s)
     with open(PATH, "w") as f:
         f.write(s)
-    print("pieces before the wait:", issued_before_wait)
+    print("pieces before the wait:", counts)
 
 
 if __name__ == "__main__":
