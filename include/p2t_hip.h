@@ -70,7 +70,9 @@ int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes
  * kernel with the split-K fix-up whenever possible; 4 = persistent, never the fix-up; 5 = persistent, partial round as
  * 128-row halves (3 / 4 / 5: the eight-wave persistent kernel); 6 = 64-deep single-barrier skeleton (experiment);
  * 7 = four-wave kernel, one tile per block; 8 = four-wave persistent kernel where eligible (what 0 picks too); 9 = the default policy without the four-wave form;
- * 10 = four-wave persistent kernel, a partial last round as whole tiles.
+ * 10 = four-wave persistent kernel, a partial last round as whole tiles; 12 = 10 with the other generated instruction order;
+ * 13 / 14 = timing experiments with WRONG results (every tile written to / also read from tile (0, 0): the same instruction
+ * stream without the round's write burst / with L2-hot operands).
  * Results are identical up to the fp32 summation order. */
 int p2t_set_gemm_policy(int policy);
 
@@ -118,7 +120,8 @@ int p2t_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, voi
 /* C[M,N] = (A8 * 2^(a_scale-127))[M,K] * (W8 * 2^(w_scale-127))[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (both scales
  * applied by the instruction), fp32 accumulate, the epilogues of p2t_gemm_nt (all but GELU_BWD).  A8 / W8: e4m3 bytes,
  * row strides lda / ldw in BYTES (multiples of 16), K % 128 == 0 with the padding zeroed; a_scale [M], w_scale [N] E8M0
- * bytes.  tile: 0 auto, 128 / 256 = tile height in rows.  P2T_EPI_GELU_FP8: out is e4m3 bytes [M, ldc bytes] (columns N up to
+ * bytes.  tile: 0 auto (the persistent four-wave kernel when the shape has no edge tiles, K % 256 == 0 and at least one tile per
+ * CU; else the per-tile kernel), 4 = four-wave kernel required, 128 / 256 = per-tile kernel of that tile height.  P2T_EPI_GELU_FP8: out is e4m3 bytes [M, ldc bytes] (columns N up to
  * the next multiple of 128 zeroed), out_row_scale the E8M0 byte of every output row (an input: see p2t_layernorm_fp8). */
 int p2t_gemm_nt_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
                     const float* bias, void* out, int64_t ldc, void* z, int64_t M, int64_t N, int64_t K, int out_dtype,

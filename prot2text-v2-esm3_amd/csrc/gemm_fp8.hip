@@ -236,6 +236,14 @@ static int launch_cfg8(const void* A, int64_t lda, const uint8_t* a_scale, const
     return P2T_OK;
 }
 
+// gemm_fp8_w4.hip: persistent four-wave form (P2T_ERR_UNSUPPORTED when the shape is not eligible)
+template <typename Epi>
+int launch_gemm_fp8_w4(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
+                       int K, int n_cover, int grid, const EpiParams& ep, hipStream_t s);
+template <typename Epi>
+constexpr bool kHasFp8W4 = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiSwiglu<bf16_t>>::value ||
+                           std::is_same<Epi, EpiQkvRope<bf16_t>>::value || std::is_same<Epi, EpiGeluFp8>::value;
+
 template <typename Epi>
 static int launch_shape8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M,
                          int N, int K, int n_cover, const EpiParams& ep, int tile, hipStream_t s) {
@@ -243,6 +251,18 @@ static int launch_shape8(const void* A, int64_t lda, const uint8_t* a_scale, con
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
+    // tile: 0 = four-wave persistent kernel when the shape allows, else the per-tile kernel below; 4 = four-wave kernel or
+    // error; 128 / 256 = per-tile eight-wave kernel of that height
+    if (tile == 0 || tile == 4) {
+        if constexpr (kHasFp8W4<Epi>) {
+            const int rc = launch_gemm_fp8_w4<Epi>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, cus, ep, s);
+            if (rc != P2T_ERR_UNSUPPORTED) return rc;
+        }
+        if (tile == 4) {
+            set_error("gemm (fp8): the four-wave kernel needs M, N %% 256 == 0, K %% 256 == 0, K >= 512, at least one tile per CU and a bf16 / fp32-residual / e4m3 epilogue");
+            return P2T_ERR_UNSUPPORTED;
+        }
+    }
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, cus);
     const double cost128 = (double)ceil_div(tm128 * tn, cus) * 0.625 * 1.08;

@@ -296,6 +296,44 @@ def test_cfg2_fp8_full_models_vs_fp8_oracle():
     observe("cfg2.fp8_vs_fp32oracle.loss", abs(loss - float(ref32["loss"])) / max(1.0, abs(float(ref32["loss"]))), 2e-1, "abs/max(1,|ref|)")
 
 
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_RESID, EPI_SWIGLU, 7])
+# one tile per CU and two K steps of pairs (the minimum) / a partial round and ten steps / many rounds, long K
+@pytest.mark.parametrize("shape", [(4096, 4096, 512), (5120, 4096, 2560), (16384, 2560, 1024), (4096, 4096, 14336)])
+def test_gemm_fp8_four_wave_kernel_vs_per_tile_kernel(ops, epi, shape):
+    """gemm_fp8_w4.hip (tile=4: persistent four-wave kernel) against the per-tile eight-wave kernel (tile=256) on the same
+    quantised operands: both sum K in the same order per accumulator, so the results are BIT identical; the per-tile
+    kernel itself is pinned on numpy and on the exact fp32-FMA kernel above."""
+    M, N, K = shape
+    a = torch.empty((M, K), dtype=torch.float32, device=dev())
+    w = torch.empty((N, K), dtype=torch.float32, device=dev())
+    ops.fill_hash_(a, 11, f"f8w4.a{M}x{K}", 1.0)
+    ops.fill_hash_(w, 11, f"f8w4.w{N}x{K}", 0.05)
+    a *= torch.exp(torch.linspace(-2.0, 2.0, M, device=dev()))[:, None]          # row scales that differ from row to row
+    w *= torch.exp(torch.linspace(1.5, -1.5, N, device=dev()))[:, None]
+    a8, sa = ops.quant_rows_fp8(a)
+    w8, sw = ops.quant_rows_fp8(w)
+    bias = None if epi == EPI_SWIGLU else to_dev(rnd(52, "f8w4.b", (N,), 0.3))
+    outs = []
+    for tile in (4, 256):
+        kw = {}
+        if epi == EPI_RESID:
+            kw["out"] = torch.ones((M, N), dtype=torch.float32, device=dev())
+        if epi == 7:
+            kw["out_row_scale"] = torch.full((M,), 127 + 2, dtype=torch.uint8, device=dev())
+        outs.append(ops.gemm_nt_fp8(a8, sa, w8, sw, bias, n=N, k=K, epilogue=epi, tile=tile, **kw))
+    assert outs[0].shape == outs[1].shape and outs[0].dtype == outs[1].dtype
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    assert bool(outs[0].float().abs().max() > 0)
+
+
+def test_gemm_fp8_four_wave_kernel_refuses_ineligible_shapes(ops):
+    a8, sa = ops.quant_rows_fp8(torch.ones((300, 512), device=dev()))
+    w8, sw = ops.quant_rows_fp8(torch.ones((256, 512), device=dev()))
+    with pytest.raises(Exception):
+        ops.gemm_nt_fp8(a8, sa, w8, sw, None, n=256, k=512, epilogue=EPI_STORE, tile=4)        # edge tile in M
+    ops.gemm_nt_fp8(a8, sa, w8, sw, None, n=256, k=512, epilogue=EPI_STORE, tile=0)            # auto: falls back to the per-tile kernel
+
+
 def test_gemm_fp8_fuzz_vs_exact_kernel(ops):
     """Random whole-tile shapes (many tiles, 2 .. 11 K steps pairs, per-row scales that differ from row to row) through the
     fp8 kernel at both tile heights against the exact fp32-FMA kernel on the dequantised operands: a stale ring slot, a

@@ -72,7 +72,7 @@ def bench_cold():
         ws, ep = ops.gemm_fix_workspace(dev), [0]
         fl = 2.0 * M * N * K / 1e9
         res = []
-        for env in ("2", "4", "3", "5", "9", "7", "8", "10", "12"):
+        for env in ("2", "4", "3", "5", "9", "7", "8", "10", "12", "13", "14"):
             _lib.call("p2t_set_gemm_policy", int(env or 0))
             tot = 0.0
             for i in range(6):
@@ -90,7 +90,7 @@ def bench_cold():
         print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
               f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | persistent+half-tiles {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f} | "
               f"eight-wave default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f} | four-wave per-tile {res[5] * 1e3:7.1f} us {fl / res[5]:7.1f} | four-wave persistent + split-K tail {res[6] * 1e3:7.1f} us {fl / res[6]:7.1f} | "
-              f"four-wave persistent, whole tiles only {res[7] * 1e3:7.1f} us {fl / res[7]:7.1f} | same, experimental order {res[8] * 1e3:7.1f} us {fl / res[8]:7.1f}", flush=True)
+              f"four-wave persistent, whole tiles only {res[7] * 1e3:7.1f} us {fl / res[7]:7.1f} | same, other order {res[8] * 1e3:7.1f} us {fl / res[8]:7.1f} | lab: all tiles written at (0,0) {res[9] * 1e3:7.1f} us {fl / res[9]:7.1f} | lab: also read from tile (0,0) {res[10] * 1e3:7.1f} us {fl / res[10]:7.1f}", flush=True)
 
 
 def bench_ksweep():
@@ -174,7 +174,10 @@ def bench_fp8():
         out = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 2 else None
         fl = 2.0 * M * N * K / 1e9
         res = []
-        for which in (256, 128, "bf16", "quant"):
+        for which in (256, 128, "bf16", "quant", 0):
+            if which == 0 and epi == 1:
+                res.append(float("nan"))                     # plain GELU has no four-wave form (the towers use GELU -> e4m3)
+                continue
             tot = 0.0
             for i in range(5):
                 flush.fill_(i)
@@ -193,7 +196,7 @@ def bench_fp8():
             res.append(tot / 4)
         print(f"fp8 {name:12s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: 256-row {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | 128-row "
               f"{res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | bf16 kernel {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | quantise A [{M}x{K}] "
-              f"{res[3] * 1e3:6.1f} us {M * K * 3 / res[3] / 1e6:6.0f} GB/s", flush=True)
+              f"{res[3] * 1e3:6.1f} us {M * K * 3 / res[3] / 1e6:6.0f} GB/s | four-wave persistent {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f}", flush=True)
 
 
 def bench_fp8abl():
