@@ -309,34 +309,40 @@ __global__ void __launch_bounds__(256)
                         slab[((h * 4 + i) * MT + j) * 256] = make_float4(acc2[h][i][j][0], acc2[h][i][j][1], acc2[h][i][j][2], acc2[h][i][j][3]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) {
+            if (w == 0) {               // wave-uniform (every lane stores the same word): no divergent region around the hand-off
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(fix.flag + t, fix.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
-            // wait for the partner (bounded spin; giving up is LOUD: sticky time-out word + NaN tiles, see gemm_mfma.hip)
-            if (threadIdx.x == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(fix.flag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fix.epoch) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 22)) {
-                        __hip_atomic_store(fix.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // wait for the partner (bounded spin; giving up is LOUD: sticky time-out word + NaN tiles, see gemm_mfma.hip).  The
+            // whole wait is ONE asm statement executed by every wave (agent-scope load of the flag, scalar compare, sleep,
+            // then the acquire's cache invalidate): no control flow the compiler can see, so the 256 accumulators stay where
+            // the K loop left them -- with a C++ spin loop the register allocator moved them across the loop and a quad came
+            // back wrong (tests/test_gpu_kernels.py::test_gemm_persistent_forms_fuzz[8])
+            {
+                const unsigned* fp = fix.flag + t;
+                unsigned seen, spins, vtmp;
+                const unsigned zero = 0;
+                asm volatile(
+                    "s_mov_b32 %1, 0\n"
+                    "1:\n\t"
+                    "global_load_dword %2, %5, %3 sc1\n\t"
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "v_readfirstlane_b32 %0, %2\n\t"
+                    "s_cmp_eq_u32 %0, %4\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "s_sleep 8\n\t"
+                    "s_add_u32 %1, %1, 1\n\t"
+                    "s_cmp_lt_u32 %1, 0x400000\n\t"
+                    "s_cbranch_scc1 1b\n"
+                    "2:\n\t"
+                    "buffer_inv sc1"
+                    : "=&s"(seen), "=&s"(spins), "=&v"(vtmp)
+                    : "s"(fp), "s"(fix.epoch), "v"(zero)
+                    : "memory", "scc");
+                if (seen != fix.epoch) __hip_atomic_store(fix.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();
-            // keep the accumulators where the K loop left them (AGPRs) across the wait: without this the compiler copies all 256
-            // to VGPRs before the spin loop and spills what does not fit
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) asm volatile("" : "+a"(acc2[h][i][j]));
             const bool timed_out = __hip_atomic_load(fix.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             const float poison = timed_out ? __builtin_nanf("") : 0.f;
             const float4* slab = reinterpret_cast<const float4*>(fix.slab) + (int64_t)t * (64 * 256) + threadIdx.x;

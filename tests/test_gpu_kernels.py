@@ -486,6 +486,29 @@ def test_gemm_four_wave_form_edges(ops, epi, shape, gemm_policy):
         assert not bool(outs[0][:, N:].any())
 
 
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_RESID])
+def test_gemm_four_wave_split_k_pairs_under_the_default_policy(ops, epi, gemm_policy):
+    """FFN-down-like shape (K = 6144 >= the default policy's threshold, 1.25 rounds of tiles): the default policy runs the
+    partial round as split-K pairs INSIDE the four-wave kernel (producer slab + consumer wait written as one asm statement);
+    against the eight-wave kernels (policy 9) on the same operands."""
+    M, N, K = 8192, 2560, 6144
+    a = torch.empty((M, K), dtype=torch.bfloat16, device=dev())
+    w = torch.empty((N, K), dtype=torch.bfloat16, device=dev())
+    ops.fill_hash_(a, 5, "w4t.a", 1.0)
+    ops.fill_hash_(w, 5, "w4t.w", 0.5)
+    b = to_dev(rnd(5, "w4t.b", (N,), 0.3))
+    ws = ops.gemm_fix_workspace(dev())
+    outs = []
+    for rep, pol in enumerate((0, 0, 9)):
+        gemm_policy(pol)
+        out = torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None
+        outs.append(ops.gemm_nt(a, w, b, epilogue=epi, out=out, out_dtype=torch.float32, use_mfma=1, fix_ws=ws, fix_epoch=100 + rep).clone())
+    assert torch.equal(outs[0], outs[1])                                   # deterministic
+    err = float((outs[0][:, :N] - outs[2][:, :N]).abs().max() / outs[2][:, :N].abs().max())
+    assert err < 2e-5, err
+    assert int(ws[1024:1028].view(torch.int32).item()) == 0
+
+
 def test_attention_fuzz_mfma_vs_simple(ops):
     """Random shapes / lengths / causal flags: the MFMA flash kernel (three-buffer prefetch, lazy rescale, XCD block order)
     against the straightforward fp32-softmax kernel on the same bf16 q, k, v."""
