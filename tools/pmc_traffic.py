@@ -70,7 +70,8 @@ def main():
     cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
     sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
     from p2t_hip import specs
-    workload = f"{cfg}/{specs.CONFIGS[cfg][3]}"                  # config / per-GPU batch of bench.py's default run
+    m = re.search(r"--batch\s+(\d+)", label)
+    workload = f"{cfg}/{int(m.group(1)) if m else specs.CONFIGS[cfg][3]}"   # config / per-GPU batch (bench.py's default unless the label carries --batch N)
     merged = defaultdict(dict)
     for sub in sorted(os.listdir(root)):
         for fam, counters in read_pass(os.path.join(root, sub)).items():
