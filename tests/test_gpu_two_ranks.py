@@ -1,0 +1,101 @@
+"""Two ranks of the REAL trainer on one GPU (both processes on cuda:0, torch.distributed over gloo -- RCCL refuses two ranks
+on one device, and the pool gives one GPU): ContrastiveTrainer.forward_backward / .step with its HIP kernels AND its
+collectives (text all-gather, label offsets, flat-gradient average, one exchange per accumulation window), against the
+single-process formulation on the concatenated global batch with contrastive_num_segments = 2 (rank == segment,
+scripts/train_contrast.py:356-379).  What the CPU gloo test (tests/test_distributed_gloo.py) drives with the oracle in
+place of the kernels, this drives end to end; only the transport (gloo instead of RCCL over xGMI) differs from an 8-GPU run.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import p2t_hip as P
+from p2t_hip import specs, synth
+from gpu_util import build_model
+rank, world, mode = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), os.environ["P2T_TEST_MODE"]
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=256, num_attention_heads=2)        # head_dim 64: fused QKV + RoPE
+llama = specs.LlamaSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=256, num_attention_heads=2, num_key_value_heads=1, vocab_size=512)
+ad = specs.AdapterSpec(esm.hidden_size, 64, llama.hidden_size, 0.0)
+B, Tp, Tt = 8, 96, 24
+pid, pmask = synth.protein_batch(7, B, Tp, [96, 90, 64, 33, 80, 17, 50, 96])
+tid, tmask = synth.text_batch(7, B, Tt, 500, [24, 20, 9, 3, 16, 24, 5, 11], 511, 510)
+model = build_model(esm, llama, ad, torch.float32, 3)
+ga = 2 if mode == "ga2" else 1
+cw = 0.5 if mode == "column" else 0.0
+if world > 1:
+    sl = slice(rank * (B // world), (rank + 1) * (B // world))
+    tr = P.ContrastiveTrainer(model, num_segments=1, output_llm_layer=2, train_mode=False, lr=1e-3, global_negatives=(mode != "local"),
+                              gradient_accumulation_steps=ga, column_weight=cw)
+else:
+    sl = slice(0, B)
+    tr = P.ContrastiveTrainer(model, num_segments=2, output_llm_layer=2, train_mode=False, lr=1e-3, gradient_accumulation_steps=ga, column_weight=cw)
+def batch(perm=None):
+    idx = np.arange(B) if perm is None else perm
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx][sl] if world == 1 else a[idx][sl])).cuda()
+    return dict(protein_input_ids=f(pid), protein_attention_mask=f(pmask), description_input_ids=f(tid), description_attention_mask=f(tmask))
+losses = []
+if ga == 1:
+    losses.append(float(tr.forward_backward(batch()).cpu()[0]))
+else:
+    # window of two micro-batches: rows permuted WITHIN each rank's share so both formulations see the same shares
+    perm = np.concatenate([np.arange(B // 2)[::-1], B // 2 + np.arange(B // 2)[::-1]])
+    losses.append(float(tr.step(batch()).cpu()[0]))
+    losses.append(float(tr.step(batch(perm)).cpu()[0]))
+g = tr.flat_g.detach().cpu().numpy().astype(np.float64)
+p = tr.flat_p.detach().cpu().numpy().astype(np.float64) if hasattr(tr, "flat_p") else np.zeros(1)
+if world > 1:
+    t = torch.tensor(losses, dtype=torch.float64)
+    dist.all_reduce(t)                       # mean over ranks = the global loss (equal shares)
+    losses = (t / world).tolist()
+if rank == 0:
+    json.dump({"loss": losses, "g_norm": float(np.linalg.norm(g)), "g": g[::97].tolist(), "p": p[::97].tolist()}, open(os.environ["P2T_TEST_OUT"], "w"))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, mode, tmp_path):
+    out = str(tmp_path / f"w{world}_{mode}.json")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   P2T_TEST_MODE=mode, P2T_TEST_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("mode", ["global", "ga2", "column"])
+def test_two_ranks_on_one_gpu_equal_the_single_process_segmented_step(mode, tmp_path):
+    two = _run(2, mode, tmp_path)
+    one = _run(1, mode, tmp_path)
+    assert np.allclose(two["loss"], one["loss"], rtol=2e-5, atol=2e-6), (two["loss"], one["loss"])
+    g2, g1 = np.array(two["g"]), np.array(one["g"])
+    assert np.linalg.norm(g2 - g1) <= 2e-4 * max(np.linalg.norm(g1), 1e-12), (np.linalg.norm(g2 - g1), np.linalg.norm(g1))
+    if mode == "ga2":                          # the optimizer ran once at the end of the window: same parameters
+        p2, p1 = np.array(two["p"]), np.array(one["p"])
+        assert np.linalg.norm(p2 - p1) <= 1e-5 * max(np.linalg.norm(p1), 1e-12)
