@@ -342,7 +342,7 @@ def main():
                        "step_tflops_per_gpu": round(step_tflops, 1), "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                        "loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma",
-                         "kernel": ("gemm_nt_fp8_kernel (e4m3 16x16x128 block-scaled MFMA GEMM, all epilogues)" if fp8 else
+                         "kernel": ("gemm_nt_fp8_w4_kernel + gemm_nt_fp8_kernel (e4m3 16x16x128 block-scaled MFMA GEMM: four-wave persistent form, eight-wave per-tile form, all epilogues)" if fp8 else
                                     "gemm_nt_w4_kernel + gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: four-wave persistent form, eight-wave persistent / per-tile / split-K-tail forms, all epilogues)"),
                          "achieved": round(achieved, 1), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), 4),
