@@ -474,6 +474,11 @@ template <typename Epi>
 int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
                            const EpiParams& ep, const SplitFix& fix, hipStream_t s, int sched);
 template <typename Epi>
+int launch_gemm_w4_pairs(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_tail, const EpiParams& ep,
+                         const SplitFix& fix, hipStream_t s);
+template <typename Epi>
+constexpr bool kHasW4Pairs = std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value;
+template <typename Epi>
 constexpr bool kHasW4 = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiStore<float>>::value || std::is_same<Epi, EpiResid>::value ||
                         std::is_same<Epi, EpiQkvRope<bf16_t>>::value || std::is_same<Epi, EpiGelu<bf16_t>>::value || std::is_same<Epi, EpiSwiglu<bf16_t>>::value;
 
@@ -523,6 +528,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (tile == 0) tile = g_gemm_policy.load(std::memory_order_relaxed);
     const bool no_w4 = tile == 9;                           // 9: the default policy without the four-wave form (A/B runs)
     if (no_w4) tile = 0;
+    const int policy_in = tile;                             // (the persistent block below folds some values into 0)
     if (tile == 6) {                                        // experiment: 64-deep single-barrier skeleton of gemm_fp8.hip
         extern int launch_gemm_bf16_k64(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, hipStream_t);
         const int rc = launch_gemm_bf16_k64(A, lda, W, ldw, M, N, K, n_cover, std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiStore<float>>::value || std::is_same<Epi, EpiGelu<float>>::value ? P2T_F32 : P2T_BF16,
@@ -610,6 +616,32 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);
     const double cost128 = (double)ceil_div(tm128 * tn, kCUs) * kSmallTileCost * 1.08;
+    if constexpr (std::is_same<Epi, EpiQkvRope<bf16_t>>::value || std::is_same<Epi, EpiStore<bf16_t>>::value) {
+        // three quarters of a round or more, but less than one (QKV of the text tower at 2 048 tokens: 192 tiles): one tile per block
+        // on the four-wave kernel (1 319 vs 1 163 TFLOP/s for the eight-wave per-tile kernel; below that fill, or with the fp32
+        // read-modify-write epilogue, the eight-wave forms stay ahead)
+        const int64_t total = tm256 * tn;
+        if (policy_in == 0 && !no_w4 && total < kCUs && total * 4 >= kCUs * 3 && K % 128 == 0 && K >= 256 && M % 256 == 0 && N % 256 == 0 && n_cover == N) {
+            extern int launch_gemm_w4(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, hipStream_t);
+            const int rc = launch_gemm_w4(A, lda, W, ldw, M, N, K, n_cover, P2T_BF16, std::is_same<Epi, EpiQkvRope<bf16_t>>::value ? P2T_EPI_QKV_ROPE : P2T_EPI_STORE, ep, s);
+            if (rc != P2T_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    if constexpr (kHasW4Pairs<Epi>) {
+        // at most half a round of 256 x 256 tiles and a long K (FFN-down of the text tower at 2 048 tokens: 128 tiles, K = 14 336):
+        // every tile as a split-K pair on the four-wave kernel -- two CUs per tile, half the K loop each (gemm_w4.hip, PAIRS_ONLY):
+        // 185 vs 204 us for the eight-wave pair kernel; at K = 4 096 (o-proj) the slab hand-off costs more than it saves (81 vs 73 us)
+        const int64_t total = tm256 * tn;
+        if (policy_in == 0 && !no_w4 && fix_ws && total * 2 <= kCUs && total * 8 >= kCUs * 3 && K % 128 == 0 && K >= 8192 && M % 256 == 0 && N % 256 == 0 &&
+            n_cover == N && (int64_t)256 * (lda > ldw ? lda : ldw) * 2 < ((int64_t)1 << 32) && fix_bytes >= kFixHeader + (size_t)total * kFixSlab) {
+            SplitFix f4;
+            f4.flag = (unsigned*)fix_ws;
+            f4.timeout = (unsigned*)((char*)fix_ws + 1024);
+            f4.slab = (float*)((char*)fix_ws + kFixHeader);
+            f4.epoch = fix_epoch;
+            return launch_gemm_w4_pairs<Epi>(A, lda, W, ldw, M, N, K, (int)total, ep, f4, s);
+        }
+    }
     if (tile == 0 && fix_ws && tm256 * tn * 2 <= kCUs && tm256 * tn * 8 >= kCUs * 3 && (K >> 5) >= 256 &&
         fix_bytes >= kFixHeader + (size_t)(tm256 * tn) * kFixSlab) {
         // at most half a round of 256-row tiles and a long K (FFN-down of the text tower: 128 tiles, K = 14336): every

@@ -25,7 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // an epilogue waits with a count that leaves the epilogue's operations in flight (Epi::kMinOps is a lower bound of them: the
 // persistent form only takes shapes without edge tiles, where every wave issues all of them).  Requires M % 256 == 0,
 // N % 256 == 0 == n_cover, K % 128 == 0, K >= 256.  !PERSIST: one tile per block, any M / N (rows clamped, edge epilogue).
-template <typename Epi, bool PERSIST, int SCHED = 0>
+template <typename Epi, bool PERSIST, int SCHED = 0, bool PAIRS_ONLY = false>
 __global__ void __launch_bounds__(256)
     gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M, int N, int K,
                       int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix, int lab = 0) {
@@ -238,6 +238,9 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                 for (int j = 0; j < MT; ++j) asm volatile("" : "+a"(acc[h][i][j]));
     };
+    // PAIRS_ONLY (a grid of at most half a round of tiles with a long K: o-proj / FFN-down of the text tower): no whole tiles,
+    // every tile runs as a split-K pair below (n_items == 0, grid = 2 n_tail)
+    if constexpr (!PAIRS_ONLY) {
     prologue();
     {
         f32x4 acc[2][4][MT];            // [64-column group of the wave][W fragment][activation fragment]
@@ -279,6 +282,7 @@ __global__ void __launch_bounds__(256)
             m0 = nm0;
             n0 = nn0;
         }
+    }
     }
     // The partial last round: blocks [0, 2 n_tail) take one half of tile n_items + t each -- the SECOND K half as producer
     // (blocks [0, n_tail): publishes the raw accumulators, never waits) or the FIRST K half as consumer (blocks [n_tail,
@@ -376,6 +380,20 @@ int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ld
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }
+// Every tile as a split-K pair (no whole tiles): n_tail tiles, grid 2 n_tail <= CUs.  Caller guarantees the persistent form's
+// shape conditions and K >= 1024.
+template <typename Epi>
+int launch_gemm_w4_pairs(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_tail, const EpiParams& ep,
+                         const SplitFix& fix, hipStream_t s) {
+    gemm_nt_w4_kernel<Epi, true, 1, true><<<dim3((unsigned)(2 * n_tail)), 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256),
+                                                                                      N / 256, 0, n_tail, N, ep, fix, 0);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+template int launch_gemm_w4_pairs<EpiResid>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_pairs<EpiStore<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+template int launch_gemm_w4_pairs<EpiStore<float>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, const EpiParams&, const SplitFix&, hipStream_t);
+
 template int launch_gemm_w4_persist<EpiStore<bf16_t>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
 template int launch_gemm_w4_persist<EpiStore<float>>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);
 template int launch_gemm_w4_persist<EpiResid>(const void*, int64_t, const void*, int64_t, int64_t, int, int, int, int, int, const EpiParams&, const SplitFix&, hipStream_t, int);

@@ -509,6 +509,29 @@ def test_gemm_four_wave_split_k_pairs_under_the_default_policy(ops, epi, gemm_po
     assert int(ws[1024:1028].view(torch.int32).item()) == 0
 
 
+@pytest.mark.parametrize("epi", [EPI_STORE, EPI_RESID])
+@pytest.mark.parametrize("shape", [(2048, 4096, 8192), (2048, 4096, 14336), (1536, 4096, 8192)])
+def test_gemm_four_wave_every_tile_as_a_split_k_pair(ops, epi, shape, gemm_policy):
+    """Text-tower shapes at 2 048 tokens (128 / 96 tiles = at most half a round): the default policy runs EVERY tile as a split-K
+    pair on the four-wave kernel (gemm_w4.hip PAIRS_ONLY); against the eight-wave forms (policy 9) on the same operands."""
+    M, N, K = shape
+    a = torch.empty((M, K), dtype=torch.bfloat16, device=dev())
+    w = torch.empty((N, K), dtype=torch.bfloat16, device=dev())
+    ops.fill_hash_(a, 6, f"w4p.a{K}", 1.0)
+    ops.fill_hash_(w, 6, f"w4p.w{K}", 0.5)
+    b = to_dev(rnd(6, "w4p.b", (N,), 0.3))
+    ws = ops.gemm_fix_workspace(dev())
+    outs = []
+    for rep, pol in enumerate((0, 0, 9)):
+        gemm_policy(pol)
+        out = torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None
+        outs.append(ops.gemm_nt(a, w, b, epilogue=epi, out=out, out_dtype=torch.float32, use_mfma=1, fix_ws=ws, fix_epoch=200 + rep).clone())
+    assert torch.equal(outs[0], outs[1])
+    err = float((outs[0][:, :N] - outs[2][:, :N]).abs().max() / outs[2][:, :N].abs().max())
+    assert err < 2e-5, err
+    assert int(ws[1024:1028].view(torch.int32).item()) == 0
+
+
 def test_attention_fuzz_mfma_vs_simple(ops):
     """Random shapes / lengths / causal flags: the MFMA flash kernel (three-buffer prefetch, lazy rescale, XCD block order)
     against the straightforward fp32-softmax kernel on the same bf16 q, k, v."""
