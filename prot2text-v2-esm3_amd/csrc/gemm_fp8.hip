@@ -253,7 +253,7 @@ static int launch_shape8(const void* A, int64_t lda, const uint8_t* a_scale, con
     if (cus <= 0) cus = 256;
     // tile: 0 = four-wave persistent kernel when the shape allows, else the per-tile kernel below; 4 = four-wave kernel or
     // error; 128 / 256 = per-tile eight-wave kernel of that height
-    if (tile == 0 || tile == 4) {
+    if ((tile == 0 && get_gemm_policy() != 9) || tile == 4) {      // p2t_set_gemm_policy(9): without the four-wave forms (A/B, identity tests)
         if constexpr (kHasFp8W4<Epi>) {
             const int rc = launch_gemm_fp8_w4<Epi>(A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, cus, ep, s);
             if (rc != P2T_ERR_UNSUPPORTED) return rc;

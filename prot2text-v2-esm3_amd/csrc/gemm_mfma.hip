@@ -516,6 +516,7 @@ static int cu_count() {
 // call, deliberately not an environment variable: nothing outside the caller's control changes kernel selection.
 static std::atomic<int> g_gemm_policy{0};
 void set_gemm_policy(int policy) { g_gemm_policy.store(policy, std::memory_order_relaxed); }
+int get_gemm_policy() { return g_gemm_policy.load(std::memory_order_relaxed); }
 
 // Layout of the split-K fix-up workspace: [0, 1024) flag words, [1024, 1088) timeout word, [2048, ...) slabs.
 constexpr size_t kFixHeader = 2048, kFixSlab = 256 * 256 * sizeof(float);

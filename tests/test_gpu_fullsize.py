@@ -151,6 +151,37 @@ def test_cfg3_batch_size_invariance_across_kernel_forms(cfg3):
     assert rel(t_big[20:24], t_small) < 1e-3
 
 
+def test_cfg3_four_wave_kernels_are_bit_identical_to_the_eight_wave_forms(cfg3):
+    """The whole cfg3 forward (16 x 1024 residues: every encoder GEMM on the persistent four-wave kernel, FFN-down with in-kernel
+    split-K pairs; 64 x 128 tokens: text-tower QKV one tile per block, FFN-down as pairs on every tile) under the default policy
+    and with the four-wave forms switched off (policy 9): every accumulator sums its K chunks in the same order in both, so the
+    pooled embeddings are BIT identical -- any stale LDS read, mis-counted wait or wrong epilogue in the new kernels shows here,
+    in the shapes and epilogues the benchmark runs.  Then the same with fp8 tower GEMMs (gemm_fp8_w4.hip vs gemm_fp8.hip)."""
+    from p2t_hip import _lib
+    P, model = cfg3["P"], cfg3["model"]
+    Tp, Tt = cfg3["Tp"], cfg3["Tt"]
+    pid, pmask = synth.protein_batch(43, 16, Tp, [Tp - 11 * i for i in range(16)])
+    tid, tmask = synth.text_batch(43, 64, Tt, 128000, [Tt - (i % 40) for i in range(64)], 128002, 128009)
+
+    def both():
+        with torch.no_grad():
+            return (P.l2_normalize(P.get_sequence_embeddings(model, to_dev(pid), to_dev(pmask))).clone(),
+                    P.l2_normalize(P.get_description_embeddings(model, to_dev(tid), to_dev(tmask), 16)).clone())
+    try:
+        for gemm_dtype in ("model", "fp8"):
+            model.set_gemm_dtype(gemm_dtype)
+            _lib.call("p2t_set_gemm_policy", 0)
+            p0, t0 = both()
+            _lib.call("p2t_set_gemm_policy", 9)
+            p9, t9 = both()
+            assert bool(torch.isfinite(p0).all()) and bool(torch.isfinite(t0).all())
+            assert torch.equal(p0, p9), (gemm_dtype, float((p0 - p9).abs().max()))
+            assert torch.equal(t0, t9), (gemm_dtype, float((t0 - t9).abs().max()))
+    finally:
+        _lib.call("p2t_set_gemm_policy", 0)
+        model.set_gemm_dtype("model")
+
+
 def test_cfg3_ragged_batch_trimmed_segments_equal_padded_step(cfg3):
     """16 pairs with log-normal lengths at full model size: the length-sorted step with per-segment padded lengths
     (persistent GEMMs with half-tile / split-K tails on odd row counts, text tower in its own length order) reproduces the
