@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--segments", type=int, default=1, help="contrastive_num_segments")
     ap.add_argument("--eval-mode", action="store_true", help="no adapter dropout (default: train mode, p=0.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="REHEARSAL, not a measurement: all --gpus N ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one "
+                         "device) -- runs this script's own multi-rank path (launcher, rank setup, barriers, max-over-ranks timing, the "
+                         "trainer's collectives) on a one-GPU box; the JSON line says so in `data`")
     ap.add_argument("--gemm-policy", type=int, default=0, help="p2t_set_gemm_policy for A/B runs (0 = the library's default; include/p2t_hip.h)")
     ap.add_argument("--event-steps", type=int, default=3,
                     help="timed steps whose MFMA launches are bracketed by HIP events for the roofline block "
@@ -247,6 +251,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     n_dev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if args.rehearse_shared_gpu:
+        local = 0
     if local >= n_dev:
         raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} needs {args.gpus} GPUs on this node, it exposes {n_dev} "
                          f"(one process per GPU; there is no CPU or shared-GPU fallback)")
@@ -258,7 +264,10 @@ def main():
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_shared_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     esm_name, llama_name, dtype_name, B, Tp, Tt = specs.CONFIGS[args.config]
     B = args.batch or B
@@ -330,12 +339,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8-e4m3 weights and GEMM operands (per-row E8M0 scales, fp8 MFMA), bf16 activations" if fp8 else dtype_name,
-            "data": "synthetic",
+            "data": "synthetic" if not args.rehearse_shared_gpu else f"synthetic (REHEARSAL: {world} ranks share one GPU over gloo -- not a scaling measurement)",
             "config": {"workload": f"{args.config}: {esm_name} + {llama_name} (text layers 1-16), per-GPU batch {B} x {Tp} residues / "
                                    f"{B} x {Tt} text tokens, readout mix, InfoNCE tau=0.05, adapter fwd+bwd + clip + AdamW, "
                                    f"{'train mode (dropout 0.3)' if not args.eval_mode else 'eval mode'}, segments {args.segments}",
                        "global_batch": world * B,
-                       "parallelism": (f"dp{dist.get_world_size()} over {dist.get_backend()} (RCCL): {dist.get_world_size()} processes, one GPU each; "
+                       "parallelism": (f"dp{dist.get_world_size()} over {dist.get_backend()}{' (RCCL)' if dist.get_backend() == 'nccl' else ''}: {dist.get_world_size()} processes, "
+                                       f"{'one GPU each' if not args.rehearse_shared_gpu else 'ALL ON ONE GPU (rehearsal)'}; "
                                        "text-embedding all-gather + one adapter-gradient all-reduce per step") if world > 1
                                       else "dp1 (single process, no collective)",
                        "algorithmic_tflop_per_sample": round(f["total"] / 1e12, 4),

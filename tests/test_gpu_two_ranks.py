@@ -99,3 +99,19 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_segmented_step(mode, tmp_
     if mode == "ga2":                          # the optimizer ran once at the end of the window: same parameters
         p2, p1 = np.array(two["p"]), np.array(one["p"])
         assert np.linalg.norm(p2 - p1) <= 1e-5 * max(np.linalg.norm(p1), 1e-12)
+
+
+def test_bench_py_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2 --rehearse-shared-gpu`: bench.py's OWN multi-rank path (self-launch of the ranks, rank setup, barriers,
+    max-over-ranks timing, rank 0's JSON line, the trainer's collectives) with both ranks on the one GPU over gloo."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--config", "cfg2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-batch64-check"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "REHEARSAL" in d["data"]
+    assert d["config"]["global_batch"] == 2 * 32 and "gloo" in d["config"]["parallelism"]
+    assert np.isfinite(d["config"]["loss"])
