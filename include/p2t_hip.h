@@ -70,9 +70,7 @@ int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes
  * kernel with the split-K fix-up whenever possible; 4 = persistent, never the fix-up; 5 = persistent, partial round as
  * 128-row halves (3 / 4 / 5: the eight-wave persistent kernel); 6 = 64-deep single-barrier skeleton (experiment);
  * 7 = four-wave kernel, one tile per block; 8 = four-wave persistent kernel where eligible (what 0 picks too); 9 = the default policy without the four-wave forms (bf16 and fp8);
- * 10 = four-wave persistent kernel, a partial last round as whole tiles; 12 = 10 with the other generated instruction order;
- * 13 / 14 = timing experiments with WRONG results (every tile written to / also read from tile (0, 0): the same instruction
- * stream without the round's write burst / with L2-hot operands).
+ * 10 = four-wave persistent kernel, a partial last round as whole tiles; 12 = 10 with the other generated instruction order.
  * Results are identical up to the fp32 summation order. */
 int p2t_set_gemm_policy(int policy);
 

@@ -141,7 +141,7 @@ extern "C" int p2t_prof_enable(int on) {
 }
 
 extern "C" int p2t_set_gemm_policy(int policy) {
-    P2T_REQUIRE(policy == 0 || policy == 1 || policy == 2 || policy == 3 || policy == 4 || policy == 5 || policy == 6 || policy == 7 || policy == 8 || policy == 9 || policy == 10 || policy == 12 || policy == 13 || policy == 14 || policy == 128 || policy == 256,
+    P2T_REQUIRE(policy == 0 || policy == 1 || policy == 2 || policy == 3 || policy == 4 || policy == 5 || policy == 6 || policy == 7 || policy == 8 || policy == 9 || policy == 10 || policy == 12 || policy == 128 || policy == 256,
                 "p2t_set_gemm_policy: unknown policy %d", policy);
     set_gemm_policy(policy);
     return P2T_OK;

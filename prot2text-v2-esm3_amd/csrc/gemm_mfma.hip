@@ -563,7 +563,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
         // 0.4 % of the step; with it hot in the Infinity Cache, as in the micro-benchmark, the per-tile kernel is 6 % ahead)
         const int64_t rem = items % kCUs;
         const bool eligible = items >= kCUs && (ns & 3) == 0 && ns >= 12 && M % 256 == 0 && N % 256 == 0 && n_cover == N;
-        const bool pick = tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || tile == 12 || tile == 13 || tile == 14 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
+        const bool pick = tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || tile == 12 || (tile == 0 && (rem == 0 || ns >= 128 || items >= 4 * kCUs || Epi::kRmw));
         if (eligible && pick) {
             int64_t n_full = items, n_tail = 0;
             int half_tail = 0;
@@ -588,8 +588,8 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
             if constexpr (kHasW4<Epi>) {
                 // four-wave form (gemm_w4.hip): the tiles of a partial last round run as split-K pairs inside the same
                 // persistent stream (tile == 10: as whole tiles)
-                const int sched = tile == 12 ? 0 : (tile == 13 ? 3 : (tile == 14 ? 4 : 1));   // 13: lab, every tile written at (0, 0)             // 12: the other instruction order of the four-wave K loop (tools/gen_w4_schedule.py)
-                if (tile == 12 || tile == 13 || tile == 14) tile = 10;
+                const int sched = tile == 12 ? 0 : 1;             // 12: the other instruction order of the four-wave K loop (tools/gen_w4_schedule.py)
+                if (tile == 12) tile = 10;
                 const bool w4 = !no_w4 && (tile == 0 || tile == 8 || tile == 10) && (int64_t)256 * (lda > ldw ? lda : ldw) * 2 < ((int64_t)1 << 32) && ns >= 8;
                 if (w4) {
                     SplitFix f4{};
@@ -612,7 +612,7 @@ static int launch_shape(const void* A, int64_t lda, const void* W, int64_t ldw, 
             P2T_LAUNCH_CHECK();
             return P2T_OK;
         }
-        if (tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || tile == 12 || tile == 13 || tile == 14) tile = 0;
+        if (tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 8 || tile == 10 || tile == 12) tile = 0;
     }
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, kCUs);

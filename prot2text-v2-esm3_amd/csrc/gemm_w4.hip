@@ -28,7 +28,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <typename Epi, bool PERSIST, int SCHED = 0, bool PAIRS_ONLY = false>
 __global__ void __launch_bounds__(256)
     gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M, int N, int K,
-                      int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix, int lab = 0) {
+                      int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix) {
     constexpr int MT = 8, NT = 8, BUF = 512 * 128, WOFF = 256 * 128, NL = 16;
     constexpr int kEpiOps = 2 * MT * Epi::kMinOps;
     constexpr int kIssuedBeforeWait = SCHED == 0 ? 6 : 9;    // DMA pieces of stage s+2 a wave has issued when it waits for stage s+1 (tools/gen_w4_schedule.py)
@@ -223,8 +223,8 @@ __global__ void __launch_bounds__(256)
             stage(acc, I1{}, F{}, F{}, false, true);
         }
         if (has_next) {                                 // the last two stages issue the next tile's first two
-            a_ptr = (const char*)(A + (lab == 2 ? 0 : nm0) * lda);          // lab 2: every tile also READS tile (0, 0): operands L2-hot
-            w_ptr = (const char*)(W + (int64_t)(lab == 2 ? 0 : nn0) * ldw);
+            a_ptr = (const char*)(A + nm0 * lda);
+            w_ptr = (const char*)(W + (int64_t)nn0 * ldw);
         }
         stage(acc, I0{}, F{}, T{}, false, has_next);
         stage(acc, I1{}, F{}, T{}, false, has_next);   // (without a next tile its fragment reads fetch stale LDS: unused)
@@ -260,12 +260,8 @@ __global__ void __launch_bounds__(256)
                 // launder the lane coordinates so the per-row output addresses are rebuilt per tile instead of being held across the K loop
                 int fr_e = fr, kg_e = kg;
                 asm volatile("" : "+v"(fr_e), "+v"(kg_e));
-                // lab (p2t_set_gemm_policy(13), timing experiments only): every tile's epilogue targets tile (0, 0) -- the same
-                // instruction stream without the round's 32 MB write burst
-                const int64_t em0 = lab ? 0 : m0;
-                const int en0 = lab ? 0 : n0;
-                tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, n_cover, em0, en0, wm, 2 * wn, fr_e, kg_e);
-                tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, n_cover, em0, en0, wm, 2 * wn + 1, fr_e, kg_e);
+                tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr_e, kg_e);
+                tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr_e, kg_e);
             } else {
                 const bool interior = m0 + 256 <= M && n0 + 256 <= N && n0 + 256 <= n_cover;
                 if (interior) {
@@ -373,8 +369,8 @@ template <typename Epi>
 int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
                            const EpiParams& ep, const SplitFix& fix, hipStream_t s, int sched) {
     const dim3 g((unsigned)(grid < n_items ? grid : n_items));
-    if (sched == 1 || sched == 3 || sched == 4)
-        gemm_nt_w4_kernel<Epi, true, 1><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix, sched == 3 ? 1 : (sched == 4 ? 2 : 0));
+    if (sched == 1)
+        gemm_nt_w4_kernel<Epi, true, 1><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
     else
         gemm_nt_w4_kernel<Epi, true, 0><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
     P2T_LAUNCH_CHECK();
@@ -386,7 +382,7 @@ template <typename Epi>
 int launch_gemm_w4_pairs(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_tail, const EpiParams& ep,
                          const SplitFix& fix, hipStream_t s) {
     gemm_nt_w4_kernel<Epi, true, 1, true><<<dim3((unsigned)(2 * n_tail)), 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256),
-                                                                                      N / 256, 0, n_tail, N, ep, fix, 0);
+                                                                                      N / 256, 0, n_tail, N, ep, fix);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

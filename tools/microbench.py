@@ -72,7 +72,7 @@ def bench_cold():
         ws, ep = ops.gemm_fix_workspace(dev), [0]
         fl = 2.0 * M * N * K / 1e9
         res = []
-        for env in ("2", "4", "3", "5", "9", "7", "8", "10", "12", "13", "14"):
+        for env in ("2", "4", "3", "5", "9", "7", "8", "10", "12"):
             _lib.call("p2t_set_gemm_policy", int(env or 0))
             tot = 0.0
             for i in range(6):
@@ -90,7 +90,7 @@ def bench_cold():
         print(f"cold {name:8s}: per-tile(+splitK) {res[0] * 1e3:7.1f} us {fl / res[0]:7.1f} TF/s | persistent {res[1] * 1e3:7.1f} us {fl / res[1]:7.1f} | "
               f"persistent+splitK {res[2] * 1e3:7.1f} us {fl / res[2]:7.1f} | persistent+half-tiles {res[3] * 1e3:7.1f} us {fl / res[3]:7.1f} | "
               f"eight-wave default {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f} | four-wave per-tile {res[5] * 1e3:7.1f} us {fl / res[5]:7.1f} | four-wave persistent + split-K tail {res[6] * 1e3:7.1f} us {fl / res[6]:7.1f} | "
-              f"four-wave persistent, whole tiles only {res[7] * 1e3:7.1f} us {fl / res[7]:7.1f} | same, other order {res[8] * 1e3:7.1f} us {fl / res[8]:7.1f} | lab: all tiles written at (0,0) {res[9] * 1e3:7.1f} us {fl / res[9]:7.1f} | lab: also read from tile (0,0) {res[10] * 1e3:7.1f} us {fl / res[10]:7.1f}", flush=True)
+              f"four-wave persistent, whole tiles only {res[7] * 1e3:7.1f} us {fl / res[7]:7.1f} | same, other order {res[8] * 1e3:7.1f} us {fl / res[8]:7.1f}", flush=True)
 
 
 def bench_ksweep():
