@@ -532,6 +532,39 @@ def test_gemm_four_wave_every_tile_as_a_split_k_pair(ops, epi, shape, gemm_polic
     assert int(ws[1024:1028].view(torch.int32).item()) == 0
 
 
+def test_gemm_four_wave_long_k_fuzz_vs_eight_wave_forms(ops, gemm_policy):
+    """Random shapes with LONG K (up to 16 384: the in-kernel split-K pairs of the default policy, pairs on every tile for grids of at
+    most half a round, whole-tile partial rounds) and every four-wave epilogue the towers use: default policy against the eight-wave
+    forms (policy 9) on the same operands -- same products, fp32 sums associated differently only where the K split differs."""
+    rng = np.random.default_rng(2024)
+    ws = ops.gemm_fix_workspace(dev())
+    epoch = 1000
+    for it in range(12):
+        if it % 3 == 2:
+            tm, tn = int(rng.integers(4, 9)), int(rng.integers(12, 17))          # 48 .. 128 tiles: at most half a round
+        else:
+            tiles = int(rng.integers(260, 700))
+            tm = int(rng.choice([d for d in range(4, 40) if tiles // d >= 4]))
+            tn = max(4, tiles // tm)
+        M, N, K = 256 * tm, 256 * tn, 128 * int(rng.integers(40, 129))
+        a = torch.empty((M, K), dtype=torch.bfloat16, device=dev())
+        w = torch.empty((N, K), dtype=torch.bfloat16, device=dev())
+        ops.fill_hash_(a, 4, f"lk.a{it}", 1.0)
+        ops.fill_hash_(w, 4, f"lk.w{it}", 0.5)
+        b = to_dev(rnd(4, f"lk.b{it}", (N,), 0.3))
+        for epi in (EPI_STORE, EPI_RESID, EPI_GELU):
+            outs = []
+            for pol in (0, 9):
+                gemm_policy(pol)
+                epoch += 1
+                out = torch.ones((M, N), dtype=torch.float32, device=dev()) if epi == EPI_RESID else None
+                outs.append(ops.gemm_nt(a, w, b, epilogue=epi, out=out, out_dtype=torch.float32 if epi == EPI_RESID else torch.bfloat16,
+                                        use_mfma=1, fix_ws=ws, fix_epoch=epoch).float().clone())
+            err = float((outs[0][:, :N] - outs[1][:, :N]).abs().max() / outs[1][:, :N].abs().max())
+            assert err < (1e-5 if epi == EPI_RESID else 8e-3), (M, N, K, epi, err)       # bf16 outputs: one rounding step at most
+    assert int(ws[1024:1028].view(torch.int32).item()) == 0
+
+
 def test_attention_fuzz_mfma_vs_simple(ops):
     """Random shapes / lengths / causal flags: the MFMA flash kernel (three-buffer prefetch, lazy rescale, XCD block order)
     against the straightforward fp32-softmax kernel on the same bf16 q, k, v."""
