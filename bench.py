@@ -58,9 +58,11 @@ def parse():
                     help="timed steps whose MFMA launches are bracketed by HIP events for the roofline block "
                          "(default: the last 3 of the timed steps -- the event records cost ~1.5 % of the step when on every launch; "
                          "-1 = all, 0 = none)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="text tower and encoder segments on separate HIP streams (+1-3 %% throughput; per-kernel event times "
-                         "then include co-running kernels, so the roofline block is only meaningful without it)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="timed region on ONE HIP stream.  Default: the text tower and the encoder segments on separate HIP streams "
+                         "(ContrastiveTrainer(overlap_streams=True): co-scheduled kernels fill each other's partial rounds, +2-3 %%); the "
+                         "roofline block's per-kernel event times always come from a separate single-stream pass after the timed region")
+    ap.add_argument("--overlap", action="store_true", help="(default since round 3; accepted for old command lines)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="pairs of the benchmarked config in the CPU-baseline sample")
     ap.add_argument("--cpu-cfg2", action="store_true", help="also time config 2 on the CPU (1 warm-up + 1 repetition, ~1.5 min)")
     ap.add_argument("--no-batch64-check", action="store_true",
@@ -109,7 +111,36 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs, with_cfg2=False):
+def gpu_vs_oracle_parity(model, gpu_batch, ref, n_pairs, layer):
+    """The timed configuration checked against the oracle on the pair(s) the CPU leg just computed (rows 0..n_pairs-1 of the
+    timed batch; same weights: the oracle read the GPU model's): relative L2 error of the pooled, normalised embeddings, and
+    the InfoNCE loss of those rows against the timed batch's text embeddings once with the GPU's rows and once with the
+    oracle's rows in their place (with one pair alone the loss would be log 1 = 0 on both sides).  Eval mode (no dropout),
+    the benchmark's dtype (bf16 / fp8 GEMMs) on the GPU against the fp32 oracle = the reference's CPU arithmetic."""
+    import torch
+    import p2t_hip as P
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            p = P.l2_normalize(P.get_sequence_embeddings(model, gpu_batch["protein_input_ids"][:n_pairs], gpu_batch["protein_attention_mask"][:n_pairs]))
+            t = P.l2_normalize(P.get_description_embeddings(model, gpu_batch["description_input_ids"], gpu_batch["description_attention_mask"], layer))
+            labels = torch.arange(n_pairs, device=p.device)
+            loss_fn = P.SegmentedBatchInfoNCELoss()
+            loss_gpu = float(loss_fn(p, t, labels))
+            t_mixed = t.clone()
+            t_mixed[:n_pairs] = torch.from_numpy(np.ascontiguousarray(ref["text"], dtype=np.float32)).to(t.device)
+            p_ref = torch.from_numpy(np.ascontiguousarray(ref["protein"], dtype=np.float32)).to(p.device)
+            loss_ref = float(loss_fn(p_ref, t_mixed, labels))
+    finally:
+        model.train(was_training)
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+    return {"protein_rel": round(rel(p.cpu().numpy(), ref["protein"]), 6), "text_rel": round(rel(t[:n_pairs].cpu().numpy(), ref["text"]), 6),
+            "loss_abs": round(abs(loss_gpu - loss_ref), 6), "loss_gpu": round(loss_gpu, 5), "loss_oracle_rows": round(loss_ref, 5),
+            "pairs": n_pairs, "negatives": int(t.shape[0]), "oracle": "fp32 (the reference's CPU arithmetic), same weights"}
+
+
+def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs, gpu_batch, with_cfg2=False):
     """The oracle (a numpy port of the reference algorithm, fp32) timed on the host cores, BASELINE.md section 3 protocol:
     forward + InfoNCE only; config 1 (the reference's own CPU-runnable case) with 1 warm-up + 3 timed repetitions, mean
     and min; the benchmarked config on `n_pairs` pair(s), scaled per pair ("extrapolated": the CPU time is linear in
@@ -155,6 +186,7 @@ def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs, with_cfg2=False):
     assert np.isfinite(out["loss"])
     work = dt - W.fetch_s
     return {"value": round(n_pairs / work, 5), "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "parity": gpu_vs_oracle_parity(model, gpu_batch, out, n_pairs, min(16, llama.num_hidden_layers)),
             "sample": f"{n_pairs} pair(s) of {cfg_name} (T_p={Tp}, T_t={Tt}), extrapolated per pair: fp32 numpy/OpenBLAS oracle, forward + InfoNCE, "
                       f"{cores} BLAS threads, one un-warmed repetition, {work:.1f} s of CPU work (+{W.fetch_s:.1f} s downloading the GPU model's "
                       f"weights, excluded); cfg1 (B=4, 128/64 tokens) timed in full with 1 warm-up + 3 repetitions: see `protocol`",
@@ -279,8 +311,9 @@ def main():
                                                       gemm_dtype="fp8" if fp8 else "model")
     model.esm_encoder.requires_grad_(False)
     model.llama_decoder.requires_grad_(False)
+    overlap = not args.no_overlap
     trainer = P.ContrastiveTrainer(model, num_segments=args.segments, train_mode=not args.eval_mode, global_negatives=True,
-                                  overlap_streams=args.overlap)
+                                  overlap_streams=overlap)
 
     pid, pmask = synth.protein_batch(1234 + rank, B, Tp)
     tid, tmask = synth.text_batch(1234 + rank, B, Tt)
@@ -295,20 +328,34 @@ def main():
     for _ in range(args.warmup):
         trainer.step(batch)
     barrier()
-    ev_steps = args.steps if args.event_steps < 0 else min(args.event_steps, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - ev_steps:
-            _lib.call("p2t_prof_enable", 1)
         loss = trainer.step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel event times (synchronises the recorded events; outside the timed region)
+    loss = trainer.global_loss(loss)            # mean over ranks (a copy; outside the timed region)
+    # Per-kernel event times for the roofline block: a SEPARATE pass on one stream after the timed region (with two streams an
+    # event pair around a launch also spans whatever the other stream runs meanwhile).  One un-timed step to settle, then
+    # `ev_steps` steps with every MFMA launch bracketed by HIP events on its launch stream; also timed as a whole = the
+    # single-stream rate of the same step.
+    ev_steps = args.steps if args.event_steps < 0 else min(args.event_steps, args.steps)
     ms = (ctypes.c_double * 3)()
     cnt = (ctypes.c_int64 * 3)()
     fl = (ctypes.c_double * 3)()
-    _lib.call("p2t_prof_collect", ms, cnt, fl, 3)
-    _lib.call("p2t_prof_enable", 0)
+    one_stream_rate = None
+    if ev_steps > 0:
+        trainer.overlap_streams = False
+        trainer.step(batch)
+        barrier()
+        _lib.call("p2t_prof_enable", 1)
+        t1 = time.perf_counter()
+        for i in range(ev_steps):
+            trainer.step(batch)
+        barrier()
+        one_stream_rate = world * B * ev_steps / (time.perf_counter() - t1)
+        _lib.call("p2t_prof_collect", ms, cnt, fl, 3)          # synchronises the recorded events
+        _lib.call("p2t_prof_enable", 0)
+        trainer.overlap_streams = overlap
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -362,6 +409,8 @@ def main():
                          "gemm_ms_per_step": round(ms[dom] / max(ev_steps, 1), 3), "attention_ms_per_step": round(ms[1] / max(ev_steps, 1), 3),
                          "bf16_gemm_ms_per_step": round(ms[0] / max(ev_steps, 1), 3),
                          "event_steps": ev_steps,
+                         "event_pass": f"{ev_steps} single-stream steps after the timed region (HIP events on the launch stream; the rocprofv3 "
+                                       "summary under profiles/ is `bench.py --no-overlap`)",
                          "attention_tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1)},
         }
         if fp8:
@@ -418,19 +467,10 @@ def main():
                                              "sorted_trimmed_one_stream_samples_per_s": round(r_trim1, 2),
                                              "segments_rows_x_length": [[b - a, t] for a, b, t, _ in t_trim._segments(srt, 64, Tmax)]}
             del t_trim
-        if world == 1 and not args.no_batch64_check and not args.overlap:
-            # the two towers on two HIP streams (ContrastiveTrainer(overlap_streams=True), `--overlap`): co-scheduled kernels
-            # fill each other's partial rounds.  Not the default because per-kernel durations (roofline, rocprof) then
-            # include the co-runner; measured here after and outside the timed region, same batch.
-            trainer.overlap_streams = True
-            trainer.step(batch)
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            for _ in range(3):
-                trainer.step(batch)
-            torch.cuda.synchronize()
-            out["config"]["two_stream_check"] = {"samples_per_s": round(B * 3 / (time.perf_counter() - t3), 2)}
-            trainer.overlap_streams = False
+        out["config"]["streams"] = ("text tower and encoder segments on separate HIP streams" if overlap else "one HIP stream")
+        if one_stream_rate is not None:
+            # the same step on ONE stream, taken from the event pass above (includes the ~1.5 % cost of the event records)
+            out["config"]["one_stream_check"] = {"samples_per_s": round(one_stream_rate, 2)}
         if world == 1 and not args.no_cpu_baseline:
             # forward + loss only (eval mode): the quantity the CPU baseline below measures
             trainer.evaluate(batch)
@@ -440,7 +480,7 @@ def main():
                 trainer.evaluate(batch)
             torch.cuda.synchronize()
             out["config"]["forward_only_samples_per_s"] = round(B * 3 / (time.perf_counter() - t2), 2)
-            out["cpu_baseline"] = cpu_baseline(model, esm, llama, args.config, Tp, Tt, args.cpu_sample, args.cpu_cfg2)
+            out["cpu_baseline"] = cpu_baseline(model, esm, llama, args.config, Tp, Tt, args.cpu_sample, batch, args.cpu_cfg2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -21,7 +21,7 @@
  * Python host).  Return value: P2T_OK or a negative code, text via p2t_last_error().
  * The library is re-entrant per stream.  Global state: the thread-local error string; the measurement hooks
  * (p2t_prof_*, mutex-guarded, off by default); the GEMM launch-form override (p2t_set_gemm_policy, one atomic word,
- * default 0).  No environment variable is read.
+ * default 0); one sticky fault word per GPU in device memory (p2t_fault_status).  No environment variable is read.
  */
 #ifndef P2T_HIP_H
 #define P2T_HIP_H
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define P2T_VERSION 101
+#define P2T_VERSION 102
 
 enum { P2T_OK = 0, P2T_ERR_ARG = -1, P2T_ERR_HIP = -2, P2T_ERR_UNSUPPORTED = -3 };
 enum { P2T_F32 = 0, P2T_BF16 = 1,                         /* storage dtype of weights / activations */
@@ -65,14 +65,35 @@ size_t p2t_struct_size(int which);
  * 4 B nh T^2 d, halved when causal); it then resets the record list. */
 int p2t_prof_enable(int on);
 int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes);
-/* Launch-form override of the bf16 MFMA GEMM for experiments and tests (process-wide): 0 = measured default policy;
- * 128 / 256 = force the tile height (per-tile kernels); 1 = no split-K tail; 2 = per-tile kernels only; 3 = persistent
- * kernel with the split-K fix-up whenever possible; 4 = persistent, never the fix-up; 5 = persistent, partial round as
- * 128-row halves (3 / 4 / 5: the eight-wave persistent kernel); 6 = 64-deep single-barrier skeleton (experiment);
- * 7 = four-wave kernel, one tile per block; 8 = four-wave persistent kernel where eligible (what 0 picks too); 9 = the default policy without the four-wave forms (bf16 and fp8);
- * 10 = four-wave persistent kernel, a partial last round as whole tiles; 12 = 10 with the other generated instruction order.
- * Results are identical up to the fp32 summation order. */
+/* Launch-form override of the MFMA GEMMs (process-wide, one atomic word): 0 = the measured default policy; 9 = the same
+ * policy without the four-wave kernels (bf16 and fp8) -- the eight-wave forms the bit-identity tests compare against
+ * (tests/test_gpu_fullsize.py).  Results are identical up to the fp32 summation order.  Any other value is refused by
+ * the product library: the launch-form zoo of the development rounds (forced tile heights, forced split-K, the other
+ * generated instruction order ...) is compiled into the LAB build only (csrc/Makefile `make lab`, -DP2T_LAB,
+ * tools/lab/gemm_forms_lab.h -> tools/build/libp2t_lab.so), which tools/ and tests/test_gpu_lab_forms.py load
+ * through P2T_HIP_LIB. */
 int p2t_set_gemm_policy(int policy);
+int p2t_is_lab_build(void);     /* 1: lab build, 0: product library */
+
+/* ---------------------------------------------------------------- runtime guards of the epoch loop */
+/* The reference's train_epoch / eval_epoch keep `ddp_loss = [sum of batch losses, batches seen]` and `ddp_gradnorm =
+ * [sum of gradient norms, optimizer steps]` (scripts/train_contrast.py:410-413,443-444,461-462,493-512) and look at
+ * every batch loss on the host (`loss.item()`, the "impossible batch loss" print of :431-434, the epoch NaN abort of
+ * :476-480).  p2t_epoch_accumulate keeps the same four sums on the device -- sums f32[4] = {loss sum, batches,
+ * gradient-norm sum, optimizer steps}; grad_norm may be NULL when no optimizer step ran after this batch -- and the
+ * guards as flags i32[4] = {number of impossible losses so far (NaN, inf or <= 0: the condition of :433), batch index
+ * of the first one (caller initialises to -1), OR of the GPU's sticky fault word, bit pattern of the first impossible
+ * loss}: one launch per batch, no host synchronisation; the host reads `flags` every N batches and at the epoch end.
+ *
+ * Fault word: one word per GPU, bit 0 = a split-K consumer of an MFMA GEMM gave up waiting for its producer (bounded
+ * spin, never expected: csrc/gemm_mfma.hip TILE_CONSUME, csrc/gemm_w4.hip).  While it is set every such consumer
+ * writes NaN tiles, so the loss of the step is NaN as well.  Sticky: only p2t_fault_status(clear = 1) resets it.
+ * p2t_fault_status copies it to the host (SYNCHRONOUS hipMemcpy: for epoch boundaries and tests);
+ * p2t_fault_inject sets it from a stream (tests of the guard). */
+int p2t_epoch_accumulate(const float* loss, const float* grad_norm, int batch_idx, float* sums, int32_t* flags,
+                         p2t_stream stream);
+int p2t_fault_status(unsigned* host_out, int clear);
+int p2t_fault_inject(unsigned value, p2t_stream stream);
 
 /* ---------------------------------------------------------------- synthetic data (bench / tests) */
 /* dst[i] = (int(hash24(i)) - 2^23) * scale23 + offset ; see p2t_hip/synth.py (bit-identical). */
@@ -93,8 +114,9 @@ int p2t_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, v
  * K-padding of the next GEMM).  z (GELU only, may be NULL): pre-activation, out_dtype, same stride.  EPI_RESID: out is f32 and accumulated in place.  EPI_SWIGLU: N is the
  * interleaved gate/up row count (a multiple of 64), out has N/2 columns.  use_mfma: -1 auto, 0 force FMA kernel, 1 require MFMA.
  * fix_ws (optional, p2t_gemm_fix_workspace_bytes() bytes): lets the MFMA kernel run the tiles of a last partial
- * "round" of the 256 CUs as two concurrent K halves (split-K fix-up).  Its first 2048 bytes must have been zeroed
- * (once) before a sequence of calls that pass strictly increasing fix_epoch values >= 1. */
+ * "round" of the 256 CUs as two concurrent K halves (split-K fix-up).  Its first 2048 bytes (the tiles' flag words)
+ * must have been zeroed (once) before a sequence of calls that pass strictly increasing fix_epoch values >= 1.
+ * A consumer that gives up waiting sets the GPU's fault word (see p2t_fault_status) and poisons its tile with NaN. */
 int p2t_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                 void* z, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int epilogue, int accumulate,
                 int use_mfma, void* fix_ws, size_t fix_ws_bytes, unsigned fix_epoch, p2t_stream stream);

@@ -35,10 +35,15 @@ F32 = np.float32
 # stores bf16 (weights, GEMM inputs, attention probabilities).  Accumulation is fp32 either way.
 # ---------------------------------------------------------------------------------------------
 def _bf16(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even to bf16, widened back to f32 (finite inputs; uint32 arithmetic, three in-place passes)."""
     x = np.ascontiguousarray(x, dtype=F32)
-    u = x.view(np.uint32).astype(np.uint64)
-    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
-    return r.astype(np.uint32).view(F32).reshape(x.shape)
+    u = x.view(np.uint32)
+    t = u >> np.uint32(16)
+    t &= np.uint32(1)
+    t += np.uint32(0x7FFF)
+    t += u                                               # a mantissa carry into the exponent is the correct rounding
+    t &= np.uint32(0xFFFF0000)
+    return t.view(F32).reshape(x.shape)
 
 
 def e4m3_round(x: np.ndarray) -> np.ndarray:
@@ -46,13 +51,20 @@ def e4m3_round(x: np.ndarray) -> np.ndarray:
     448, no infinities), round-to-nearest-even -- what v_cvt_pk_fp8_f32 does on gfx950 and torch.float8_e4m3fn on the
     CPU (tests/test_fp8_host.py pins this function on the latter).  |x| <= 448 is the caller's business (scaled rows)."""
     x = np.ascontiguousarray(x, dtype=F32)
-    a = np.abs(x)
-    _, ex = np.frexp(a)                                  # a = m 2^ex, m in [0.5, 1): floor(log2 a) = ex - 1
-    e = np.maximum(ex.astype(np.int32) - 1, -6)          # below 2^-6 the spacing stays that of the subnormals
-    quantum = np.ldexp(F32(1.0), e - 3).astype(F32)
-    r = (np.rint(a / quantum) * quantum).astype(F32)     # rint: ties to even; both operations are exact in f32
+    u = x.view(np.uint32)
+    a = u & np.uint32(0x7FFFFFFF)                        # |x| as bits
+    # normal range (|x| >= 2^-6): keep 3 of the 23 mantissa bits, ties to even -- the bf16 trick 20 bits lower
+    t = a >> np.uint32(20)
+    t &= np.uint32(1)
+    t += np.uint32(0x7FFFF)
+    t += a
+    t &= np.uint32(0xFFF00000)
+    r = t.view(F32)
+    small = a < np.uint32(0x3C800000)                    # below 2^-6 the spacing stays that of the subnormals, 2^-9
+    if small.any():
+        r = np.where(small, np.rint(a.view(F32) * F32(512.0)) * F32(1.0 / 512.0), r)     # rint: ties to even; both exact in f32
     r = np.minimum(r, F32(448.0))
-    return np.copysign(r, x).astype(F32)
+    return np.copysign(r, x).astype(F32, copy=False)
 
 
 def e8m0_of_amax(amax: np.ndarray) -> np.ndarray:

@@ -141,10 +141,24 @@ extern "C" int p2t_prof_enable(int on) {
 }
 
 extern "C" int p2t_set_gemm_policy(int policy) {
+#ifdef P2T_LAB
     P2T_REQUIRE(policy == 0 || policy == 1 || policy == 2 || policy == 3 || policy == 4 || policy == 5 || policy == 6 || policy == 7 || policy == 8 || policy == 9 || policy == 10 || policy == 12 || policy == 128 || policy == 256,
-                "p2t_set_gemm_policy: unknown policy %d", policy);
+                "p2t_set_gemm_policy (lab build): unknown policy %d", policy);
+#else
+    P2T_REQUIRE(policy == 0 || policy == 9, "p2t_set_gemm_policy: policy %d is not in the product library (0 = default, 9 = without the four-wave kernels; "
+                "the other launch forms are in the lab build, tools/lab/)", policy);
+#endif
     set_gemm_policy(policy);
     return P2T_OK;
+}
+
+/* 1 in the lab build (-DP2T_LAB: every launch form of rounds 1-2 selectable), 0 in the product library. */
+extern "C" int p2t_is_lab_build(void) {
+#ifdef P2T_LAB
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int p2t_prof_collect(double* ms, int64_t* launches, double* flops, int n_classes) {

@@ -299,7 +299,8 @@ int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const vo
     return P2T_ERR_ARG;
 }
 
-// experiment: bf16 operands through the 64-deep single-barrier skeleton (policy 6).  K in elements, strides in elements.
+#ifdef P2T_LAB
+// lab build only: bf16 operands through the 64-deep single-barrier skeleton (policy 6).  K in elements, strides in elements.
 template <typename Epi>
 static int launch_k64(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, const EpiParams& ep,
                       hipStream_t s) {
@@ -320,5 +321,6 @@ int launch_gemm_bf16_k64(const void* A, int64_t lda, const void* W, int64_t ldw,
     }
     return P2T_ERR_UNSUPPORTED;
 }
+#endif  // P2T_LAB
 
 }  // namespace p2t

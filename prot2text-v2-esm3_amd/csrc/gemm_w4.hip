@@ -25,11 +25,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // an epilogue waits with a count that leaves the epilogue's operations in flight (Epi::kMinOps is a lower bound of them: the
 // persistent form only takes shapes without edge tiles, where every wave issues all of them).  Requires M % 256 == 0,
 // N % 256 == 0 == n_cover, K % 128 == 0, K >= 256.  !PERSIST: one tile per block, any M / N (rows clamped, edge epilogue).
-template <typename Epi, bool PERSIST, int SCHED = 0, bool PAIRS_ONLY = false>
+template <typename Epi, bool PERSIST, int SCHED = 1, bool PAIRS_ONLY = false>
 __global__ void __launch_bounds__(256)
     gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw, int64_t M, int N, int K,
                       int tiles_m, int tiles_n, int n_items, int n_tail, int n_cover, EpiParams ep, SplitFix fix) {
     constexpr int MT = 8, NT = 8, BUF = 512 * 128, WOFF = 256 * 128, NL = 16;
+#ifndef P2T_LAB
+    static_assert(SCHED == 1, "the product library carries one instruction order of the K loop; order 0 is in the lab build");
+#endif
     constexpr int kEpiOps = 2 * MT * Epi::kMinOps;
     constexpr int kIssuedBeforeWait = SCHED == 0 ? 6 : 9;    // DMA pieces of stage s+2 a wave has issued when it waits for stage s+1 (tools/gen_w4_schedule.py)
     constexpr int kExtCount = kIssuedBeforeWait + kEpiOps > 63 ? 63 : kIssuedBeforeWait + kEpiOps;
@@ -140,26 +143,7 @@ __global__ void __launch_bounds__(256)
         else if (FI::value && ext) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kExtCount) : "memory");                 \
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kIssuedBeforeWait) : "memory");
         // GENERATED (tools/gen_w4_schedule.py) BEGIN
-        if constexpr (SCHED == 0) {
-            P2T_W4_R1W(0) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1X(0) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 3)
-            P2T_W4_R1W(3) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1W(4) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 7)
-            P2T_W4_R1X(2) P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_R1W(7) P2T_W4_PAIR(FI, wa, xa, 10) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 11)
-            P2T_W4_R1X(4) P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_R1X(6) P2T_W4_PAIR(FI, wa, xa, 14) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 15)
-            P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_PAIR(FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            P2T_W4_GPAIR(0, FI, wa, xa, 20) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_GPAIR(1, FI, wa, xa, 22) P2T_W4_PAIR(FI, wa, xa, 23)
-            P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_GPAIR(2, FI, wa, xa, 25) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_PAIR(FI, wa, xa, 27)
-            P2T_W4_GPAIR(3, FI, wa, xa, 28) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_GPAIR(4, FI, wa, xa, 31)
-            P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_GPAIR(5, F, wb, xb, 1) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_PAIR(F, wb, xb, 3)
-            P2T_W4_WAIT_NEXT_STAGE
-            P2T_W4_R0W(0) P2T_W4_GPAIR(6, F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_GPAIR(7, F, wb, xb, 7)
-            P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_GPAIR(8, F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
-            P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_GPAIR(9, F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
-            P2T_W4_R0X(4) P2T_W4_GPAIR(10, F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_GPAIR(11, F, wb, xb, 19)
-            P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_GPAIR(12, F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23)
-            P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_GPAIR(13, F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
-            P2T_W4_GPAIR(14, F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_GPAIR(15, F, wb, xb, 31)
-        } else if constexpr (SCHED == 1) {
+        if constexpr (SCHED == 1) {
             P2T_W4_R1W(0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1X(0) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1W(3) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(4) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 3)
             P2T_W4_R1X(2) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1W(7) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1X(4) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1X(6) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 7)
             P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_PAIR(FI, wa, xa, 10)
@@ -180,6 +164,28 @@ __global__ void __launch_bounds__(256)
             P2T_W4_GPAIR(15, F, wb, xb, 24) P2T_W4_PAIR(F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
             P2T_W4_PAIR(F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_PAIR(F, wb, xb, 31)
         }
+#ifdef P2T_LAB
+        else if constexpr (SCHED == 0) {
+            P2T_W4_R1W(0) P2T_W4_PAIR(FI, wa, xa, 0) P2T_W4_R1W(1) P2T_W4_PAIR(FI, wa, xa, 1) P2T_W4_R1X(0) P2T_W4_PAIR(FI, wa, xa, 2) P2T_W4_R1W(2) P2T_W4_PAIR(FI, wa, xa, 3)
+            P2T_W4_R1W(3) P2T_W4_PAIR(FI, wa, xa, 4) P2T_W4_R1X(1) P2T_W4_PAIR(FI, wa, xa, 5) P2T_W4_R1W(4) P2T_W4_PAIR(FI, wa, xa, 6) P2T_W4_R1W(5) P2T_W4_PAIR(FI, wa, xa, 7)
+            P2T_W4_R1X(2) P2T_W4_PAIR(FI, wa, xa, 8) P2T_W4_R1W(6) P2T_W4_PAIR(FI, wa, xa, 9) P2T_W4_R1W(7) P2T_W4_PAIR(FI, wa, xa, 10) P2T_W4_R1X(3) P2T_W4_PAIR(FI, wa, xa, 11)
+            P2T_W4_R1X(4) P2T_W4_PAIR(FI, wa, xa, 12) P2T_W4_R1X(5) P2T_W4_PAIR(FI, wa, xa, 13) P2T_W4_R1X(6) P2T_W4_PAIR(FI, wa, xa, 14) P2T_W4_R1X(7) P2T_W4_PAIR(FI, wa, xa, 15)
+            P2T_W4_PAIR(FI, wa, xa, 16) P2T_W4_PAIR(FI, wa, xa, 17) P2T_W4_PAIR(FI, wa, xa, 18) P2T_W4_PAIR(FI, wa, xa, 19)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P2T_W4_GPAIR(0, FI, wa, xa, 20) P2T_W4_PAIR(FI, wa, xa, 21) P2T_W4_GPAIR(1, FI, wa, xa, 22) P2T_W4_PAIR(FI, wa, xa, 23)
+            P2T_W4_PAIR(FI, wa, xa, 24) P2T_W4_GPAIR(2, FI, wa, xa, 25) P2T_W4_PAIR(FI, wa, xa, 26) P2T_W4_PAIR(FI, wa, xa, 27)
+            P2T_W4_GPAIR(3, FI, wa, xa, 28) P2T_W4_PAIR(FI, wa, xa, 29) P2T_W4_PAIR(FI, wa, xa, 30) P2T_W4_GPAIR(4, FI, wa, xa, 31)
+            P2T_W4_PAIR(F, wb, xb, 0) P2T_W4_GPAIR(5, F, wb, xb, 1) P2T_W4_PAIR(F, wb, xb, 2) P2T_W4_PAIR(F, wb, xb, 3)
+            P2T_W4_WAIT_NEXT_STAGE
+            P2T_W4_R0W(0) P2T_W4_GPAIR(6, F, wb, xb, 4) P2T_W4_R0W(1) P2T_W4_PAIR(F, wb, xb, 5) P2T_W4_R0X(0) P2T_W4_PAIR(F, wb, xb, 6) P2T_W4_R0W(2) P2T_W4_GPAIR(7, F, wb, xb, 7)
+            P2T_W4_R0W(3) P2T_W4_PAIR(F, wb, xb, 8) P2T_W4_R0X(1) P2T_W4_PAIR(F, wb, xb, 9) P2T_W4_R0W(4) P2T_W4_GPAIR(8, F, wb, xb, 10) P2T_W4_R0W(5) P2T_W4_PAIR(F, wb, xb, 11)
+            P2T_W4_R0X(2) P2T_W4_PAIR(F, wb, xb, 12) P2T_W4_R0W(6) P2T_W4_GPAIR(9, F, wb, xb, 13) P2T_W4_R0W(7) P2T_W4_PAIR(F, wb, xb, 14) P2T_W4_R0X(3) P2T_W4_PAIR(F, wb, xb, 15)
+            P2T_W4_R0X(4) P2T_W4_GPAIR(10, F, wb, xb, 16) P2T_W4_R0X(5) P2T_W4_PAIR(F, wb, xb, 17) P2T_W4_R0X(6) P2T_W4_PAIR(F, wb, xb, 18) P2T_W4_R0X(7) P2T_W4_GPAIR(11, F, wb, xb, 19)
+            P2T_W4_PAIR(F, wb, xb, 20) P2T_W4_PAIR(F, wb, xb, 21) P2T_W4_GPAIR(12, F, wb, xb, 22) P2T_W4_PAIR(F, wb, xb, 23)
+            P2T_W4_PAIR(F, wb, xb, 24) P2T_W4_GPAIR(13, F, wb, xb, 25) P2T_W4_PAIR(F, wb, xb, 26) P2T_W4_PAIR(F, wb, xb, 27)
+            P2T_W4_GPAIR(14, F, wb, xb, 28) P2T_W4_PAIR(F, wb, xb, 29) P2T_W4_PAIR(F, wb, xb, 30) P2T_W4_GPAIR(15, F, wb, xb, 31)
+        }
+#endif
         // GENERATED END
         a_ptr += 128; w_ptr += 128;
 #undef P2T_W4_WAIT_NEXT_STAGE
@@ -369,10 +375,15 @@ template <typename Epi>
 int launch_gemm_w4_persist(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_items, int n_tail, int grid,
                            const EpiParams& ep, const SplitFix& fix, hipStream_t s, int sched) {
     const dim3 g((unsigned)(grid < n_items ? grid : n_items));
-    if (sched == 1)
-        gemm_nt_w4_kernel<Epi, true, 1><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
-    else
+#ifdef P2T_LAB
+    if (sched == 0) {
         gemm_nt_w4_kernel<Epi, true, 0><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
+        P2T_LAUNCH_CHECK();
+        return P2T_OK;
+    }
+#endif
+    P2T_REQUIRE(sched == 1, "gemm (four-wave): instruction order %d is not in this build", sched);
+    gemm_nt_w4_kernel<Epi, true, 1><<<g, 256, 0, s>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, (int)(M / 256), N / 256, n_items, n_tail, N, ep, fix);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -45,6 +45,7 @@ int launch_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, 
                        int64_t cols, hipStream_t s);
 int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
                     int K, int n_cover, int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s);
+unsigned* fault_word_ptr();            // the GPU's sticky fault word (misc.hip); nullptr if the symbol cannot be resolved
 int get_gemm_policy();
 void set_gemm_policy(int policy);       // launch-form override of the MFMA GEMM (tests / experiments), 0 = default
 size_t gemm_fix_workspace_bytes();       // split-K tail fix-up workspace (flags + slabs); header must be zeroed once per

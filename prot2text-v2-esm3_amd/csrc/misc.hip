@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -15,6 +17,58 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sticky fault word + epoch bookkeeping (the reference's two runtime guards, scripts/train_contrast.py:431-434, 476-480,
+// kept on the device so the hot loop never pays a per-batch `.item()`).
+//
+// g_fault_word: one word of device-global storage per GPU, bit 0 = "a split-K consumer gave up waiting for its producer"
+// (gemm_mfma.hip / gemm_w4.hip: bounded spin).  Every split-K launch points SplitFix::timeout at it; nothing clears it except
+// p2t_fault_status(clear = 1), so a time-out stays visible to whoever looks next: consumers (they write NaN tiles while it is
+// set, so the step's loss is NaN) and p2t_epoch_accumulate (copies it into the epoch's flag block).
+__device__ unsigned g_fault_word = 0;
+
+unsigned* fault_word_ptr() {
+    static std::atomic<unsigned*> cache[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    unsigned* p = cache[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_fault_word)) != hipSuccess) return nullptr;
+        p = (unsigned*)q;
+        cache[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
+// sums[0] += loss, sums[1] += 1 (train_contrast.py:443-444: `ddp_loss[0] += batch_loss_value; ddp_loss[1] += 1`);
+// grad_norm given (an optimizer step ran): sums[2] += grad_norm, sums[3] += 1 (:461-462).
+// flags[0] = number of "impossible" batch losses so far (NaN, inf or <= 0: the condition of :433), flags[1] = batch index of
+// the first one (-1: none), flags[3] = its bit pattern; flags[2] |= the sticky fault word.
+__global__ void epoch_accumulate_kernel(const float* __restrict__ loss, const float* __restrict__ grad_norm, int batch_idx,
+                                        float* __restrict__ sums, int* __restrict__ flags, const unsigned* __restrict__ fault) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float l = loss[0];
+    sums[0] += l;
+    sums[1] += 1.0f;
+    if (grad_norm) {
+        sums[2] += grad_norm[0];
+        sums[3] += 1.0f;
+    }
+    if (!(l > 0.0f) || isinf(l)) {            // NaN fails `l > 0`
+        if (flags[0] == 0) {
+            flags[1] = batch_idx;
+            flags[3] = __float_as_int(l);
+        }
+        flags[0] += 1;
+    }
+    flags[2] |= (int)__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void fault_set_kernel(unsigned* fault, unsigned value) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(fault, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,6 +256,36 @@ extern "C" int p2t_transpose(const void* src, int64_t rows, int64_t cols, int64_
         transpose_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)src, rows, cols, ld_src, (bf16_t*)dst, ld_dst);
     else
         transpose_kernel<float><<<grid, 256, 0, s>>>((const float*)src, rows, cols, ld_src, (float*)dst, ld_dst);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_epoch_accumulate(const float* loss, const float* grad_norm, int batch_idx, float* sums, int32_t* flags,
+                                    p2t_stream stream) {
+    P2T_REQUIRE(loss && sums && flags, "p2t_epoch_accumulate: null argument");
+    unsigned* fault = fault_word_ptr();
+    P2T_REQUIRE(fault, "p2t_epoch_accumulate: no device fault word (hipGetSymbolAddress failed)");
+    epoch_accumulate_kernel<<<1, 64, 0, (hipStream_t)stream>>>(loss, grad_norm, batch_idx, sums, flags, fault);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_fault_status(unsigned* host_out, int clear) {
+    P2T_REQUIRE(host_out, "p2t_fault_status: null argument");
+    unsigned* fault = fault_word_ptr();
+    P2T_REQUIRE(fault, "p2t_fault_status: no device fault word (hipGetSymbolAddress failed)");
+    P2T_CHECK_HIP(hipMemcpy(host_out, fault, sizeof(unsigned), hipMemcpyDeviceToHost));     // synchronous by design
+    if (clear && *host_out) {
+        const unsigned zero = 0;
+        P2T_CHECK_HIP(hipMemcpy(fault, &zero, sizeof(unsigned), hipMemcpyHostToDevice));
+    }
+    return P2T_OK;
+}
+
+extern "C" int p2t_fault_inject(unsigned value, p2t_stream stream) {
+    unsigned* fault = fault_word_ptr();
+    P2T_REQUIRE(fault, "p2t_fault_inject: no device fault word (hipGetSymbolAddress failed)");
+    fault_set_kernel<<<1, 64, 0, (hipStream_t)stream>>>(fault, value);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

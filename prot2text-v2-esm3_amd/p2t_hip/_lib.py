@@ -88,6 +88,10 @@ SIGNATURES = {
     "p2t_struct_size": (sz, [i32]),
     "p2t_prof_enable": (i32, [i32]),
     "p2t_set_gemm_policy": (i32, [i32]),
+    "p2t_is_lab_build": (i32, []),
+    "p2t_epoch_accumulate": (i32, [vp, vp, i32, vp, vp, vp]),
+    "p2t_fault_status": (i32, [C.POINTER(C.c_uint), i32]),
+    "p2t_fault_inject": (i32, [C.c_uint, vp]),
     "p2t_prof_collect": (i32, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64), i32]),
     "p2t_fill_hash": (i32, [vp, i64, u64, u64, f32, f32, i32, vp]),
     "p2t_cast": (i32, [vp, i32, vp, i32, i64, vp]),
@@ -146,7 +150,7 @@ for _i, _s in enumerate(_STRUCTS):
     if lib.p2t_struct_size(_i) != C.sizeof(_s):
         raise ImportError(f"ABI mismatch: {_s.__name__} is {C.sizeof(_s)} bytes here, {lib.p2t_struct_size(_i)} in the library")
 
-_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes",
+_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_is_lab_build", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes",
           "p2t_adapter_backward_workspace_bytes"}
 
 
@@ -165,3 +169,10 @@ def call(name: str, *args):
 
 def version() -> int:
     return lib.p2t_version()
+
+
+def fault_status(clear: bool = False) -> int:
+    """The GPU's sticky fault word (bit 0: a split-K consumer timed out).  Synchronises with the device."""
+    out = C.c_uint(0)
+    call("p2t_fault_status", C.byref(out), int(bool(clear)))
+    return int(out.value)

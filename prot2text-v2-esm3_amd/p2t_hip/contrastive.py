@@ -525,11 +525,22 @@ class ContrastiveTrainer:
                  ptr(self.g[0]), ptr(self.g[1]), ptr(self.g[2]), ptr(self.g[3]), int(s > 0 or accumulate), ptr(b["ws"]),
                  b["ws"].numel(), stream())
 
+        def prefetch_fn(s, r0, r1, Ts):
+            """The first segment's encoder -> adapter -> readout, enqueued before the wait for the gathered text embeddings."""
+            states[s] = seg_forward(s, r0, r1, Ts, slot=0)
+
         sharding.sharded_forward_backward(text_fn=text_fn, segment_fn=segment_fn, segments=segs,
                                           global_negatives=self.global_negatives, flat_g=self.flat_g, backward=backward,
                                           reduce=reduce, group=self.group, protein_fn=protein_fn if cw > 0.0 else None,
-                                          column_fn=column_fn if cw > 0.0 else None)
+                                          column_fn=column_fn if cw > 0.0 else None,
+                                          prefetch_fn=prefetch_fn if (cw == 0.0 and self.global_negatives and sharding.world_info(self.group)[1] > 1) else None)
         return self.loss
+
+    def global_loss(self, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Mean over ranks of `loss` (default: the last step's) = the loss of the global batch; one tiny all-reduce, no host
+        sync.  `step()` itself returns the rank-local loss, as the reference's teacher_forcing_forward_pass does -- the
+        reference only all-reduces its epoch sums (train_contrast.py:468), which is what loop.train_epoch does too."""
+        return sharding.average_loss(self.loss if loss is None else loss, self.group)
 
     def _segments(self, batch, B: int, T: int):
         """[(start, stop, T_s, weight)]: the row ranges of the protein side, the padded length each runs at and its

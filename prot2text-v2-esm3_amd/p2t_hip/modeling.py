@@ -25,6 +25,7 @@ from typing import Optional
 
 import torch
 from torch import nn
+from transformers import PreTrainedModel
 from transformers.modeling_outputs import BaseModelOutputWithPoolingAndCrossAttentions
 
 from . import _lib, ops, specs
@@ -624,27 +625,41 @@ class LlamaDecoder(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # the assembled model
 # ---------------------------------------------------------------------------------------------
-class Esm2LlamaInstructForCausalLM(nn.Module):
+class Esm2LlamaInstructForCausalLM(PreTrainedModel):
     """Esm2LlamaInstructForCausalLM = ESM2 encoder + ModalityAdapter + Llama decoder
     (reference models/modeling_esm2llama_instruct.py:71-268).  Initialise with either a
-    configuration OR all three components; `kwargs` override standalone config attributes."""
+    configuration OR all three components; `kwargs` override standalone config attributes.
+
+    A `transformers.PreTrainedModel` like the reference's class (:71-78): `isinstance` checks, `config_class`,
+    `save_pretrained(dir, state_dict=..., safe_serialization=...)` as `transformers.Trainer.save_model` calls it,
+    `from_pretrained(dir, torch_dtype=...)`, `gradient_checkpointing_enable(gradient_checkpointing_kwargs=...)`.  The modelling
+    code is this package's (HIP kernels behind the three sub-modules), none of it is transformers'."""
     config_class = Esm2LlamaInstructConfig
+    base_model_prefix = "model"
+    main_input_name = "input_ids"
+    supports_gradient_checkpointing = True          # accepted; a no-op (the frozen towers run without autograd, see below)
+    _no_split_modules = ["EsmEncoder", "ModalityAdapter", "LlamaDecoder"]
+    _supports_sdpa = False
+    _supports_flash_attn = False
 
     def __init__(self, config: Optional[Esm2LlamaInstructConfig] = None, esm_encoder: Optional[EsmEncoder] = None,
                  adapter: Optional[ModalityAdapter] = None, llama_decoder: Optional[LlamaDecoder] = None,
                  dtype=torch.float32, device="cuda", **kwargs):
-        super().__init__()
         if config is not None:                    # components ignored if config is provided (reference :88-95)
-            self.config = config
+            super().__init__(config)
             self.esm_encoder = EsmEncoder(config.esm_config, dtype, device)
             self.adapter = ModalityAdapter(config.adapter_config, dtype, device)
             self.llama_decoder = LlamaDecoder(config.llama_config, dtype, device)
         else:
             if esm_encoder is None or adapter is None or llama_decoder is None:
                 raise ValueError("pass either `config` or all of esm_encoder, adapter and llama_decoder")
-            self.config = Esm2LlamaInstructConfig(esm_config=esm_encoder.config, adapter_config=adapter.config,
-                                                  llama_config=llama_decoder.config, **kwargs)
+            super().__init__(Esm2LlamaInstructConfig(esm_config=esm_encoder.config, adapter_config=adapter.config,
+                                                     llama_config=llama_decoder.config, **kwargs))      # reference :96-106
             self.esm_encoder, self.adapter, self.llama_decoder = esm_encoder, adapter, llama_decoder
+
+    def _init_weights(self, module):
+        """Parameters are created by the sub-modules (torch.empty) and then filled from a checkpoint or from the synthetic
+        generator (`fill_synthetic`); there is no random initialisation scheme to apply (the reference class has none either)."""
 
     # ---- synthetic construction (bench / tests: no checkpoints exist offline) ----
     @classmethod
@@ -660,13 +675,20 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
         return model.set_gemm_dtype(gemm_dtype)
 
     # ---- HF-style persistence (the reference class is a PreTrainedModel: models/modeling_esm2llama_instruct.py:71-106) ----
-    def save_pretrained(self, save_directory: str, safe_serialization: bool = True):
+    def save_pretrained(self, save_directory: str, state_dict=None, safe_serialization: bool = True, is_main_process: bool = True,
+                        **kwargs):
         """`config.json` (Esm2LlamaInstructConfig.save_pretrained) + the HF-named state dict (`esm_encoder.*`, `adapter.*`,
-        `llama_decoder.*`) as `model.safetensors` (or `pytorch_model.bin`), as `PreTrainedModel.save_pretrained` lays them out."""
+        `llama_decoder.*`) as `model.safetensors` (or `pytorch_model.bin`), as `PreTrainedModel.save_pretrained` lays them out.
+        `state_dict` / `is_main_process` / further keywords as `transformers.Trainer.save_model` passes them (sharding,
+        `push_to_hub` and friends are not supported: one file, local directory)."""
         import os
+        if kwargs.get("push_to_hub"):
+            raise ValueError("there is no hub access on this path")
+        if not is_main_process:
+            return
         os.makedirs(save_directory, exist_ok=True)
         self.config.save_pretrained(save_directory)
-        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        sd = {k: v.detach().cpu().contiguous() for k, v in (self.state_dict() if state_dict is None else state_dict).items()}
         if self.llama_decoder.spec.tie_word_embeddings:
             sd.pop("llama_decoder.lm_head.weight", None)             # tied to embed_tokens: stored once, as HF does
         if safe_serialization:
@@ -676,28 +698,39 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
             torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
 
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path: str, dtype=None, device="cuda", **kwargs):
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args, dtype=None, torch_dtype=None, device="cuda", config=None,
+                        **kwargs):
         """Local directory written by `save_pretrained` (of this class or of the reference's): config -> modules -> weights.
-        Weight files are read with loaders that execute nothing (safetensors, or torch.load(weights_only=True))."""
+        Weight files are read with loaders that execute nothing (safetensors, or torch.load(weights_only=True)).
+        `torch_dtype=` (the keyword of the reference's transformers 4.40) and `dtype=` (transformers 5) both select the
+        parameter dtype; default: the dtype the checkpoint was written in."""
         import os
         d = pretrained_model_name_or_path
         if not os.path.isdir(d):
             raise ValueError(f"{d!r} is not a local directory (there is no hub access on this path)")
-        config = Esm2LlamaInstructConfig.from_pretrained(d)
+        if config is None:
+            config = Esm2LlamaInstructConfig.from_pretrained(d)
         st = os.path.join(d, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file
             sd = load_file(st)
         else:
             sd = torch.load(os.path.join(d, "pytorch_model.bin"), weights_only=True, map_location="cpu")
+        dtype = dtype if dtype is not None else torch_dtype
+        if isinstance(dtype, str):
+            dtype = None if dtype == "auto" else getattr(torch, dtype)
         if dtype is None:
             dtype = next(iter(sd.values())).dtype
+        for k in ("low_cpu_mem_usage", "device_map", "attn_implementation", "trust_remote_code", "use_safetensors", "local_files_only"):
+            kwargs.pop(k, None)                    # loader hints of HF's implementation: nothing to do here
         model = cls(config=config, dtype=dtype, device=device, **kwargs)
         res = model.load_state_dict(sd, strict=False)
         bad = [k for k in res.missing_keys if not ("contact_head" in k or "inv_freq" in k or k.endswith("lm_head.weight"))]
         if bad or res.unexpected_keys:
             raise RuntimeError(f"checkpoint does not match the configuration: missing {bad}, unexpected {res.unexpected_keys}")
-        return model
+        model.esm_encoder.invalidate_engine()
+        model.llama_decoder.model.invalidate_engine()
+        return model.eval()                        # as PreTrainedModel.from_pretrained returns its models
 
     def set_gemm_dtype(self, gemm_dtype: str = "model"):
         """"fp8": the eight projections of both frozen towers run on the fp8 MFMA kernel -- weights quantised once to e4m3
@@ -788,8 +821,18 @@ class Esm2LlamaInstructForCausalLM(nn.Module):
     def generate(self, *args, **kwargs):
         raise NotImplementedError("generation is out of scope for the contrastive path")
 
-    def gradient_checkpointing_enable(self):
-        """No-op: the towers are frozen and run without autograd on this path (reference :253-261)."""
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        """Accepted for loop compatibility (reference :253-261; `transformers.Trainer(gradient_checkpointing=True)` passes
+        `gradient_checkpointing_kwargs`), and a no-op by construction: activation checkpointing trades recomputation for the
+        memory autograd holds, and on this path the frozen towers run WITHOUT autograd (nothing is kept), while the adapter keeps
+        one set of activations per segment (z1, h1, z2: ContrastiveTrainer._buffers) -- `contrastive_num_segments` bounds that,
+        as it does upstream."""
+        self._gradient_checkpointing_requested = True
 
     def gradient_checkpointing_disable(self):
         """No-op (reference :263-268)."""
+        self._gradient_checkpointing_requested = False
+
+    @property
+    def is_gradient_checkpointing(self) -> bool:
+        return bool(getattr(self, "_gradient_checkpointing_requested", False))

@@ -43,6 +43,45 @@ def gather_rows(x_local: torch.Tensor, group=None) -> Tuple[torch.Tensor, int]:
     return out, rank * x_local.shape[0]
 
 
+class PendingGather:
+    """An all-gather in flight (`gather_rows_async`): `wait()` makes the CURRENT stream (RCCL) or the host (gloo) wait for it and
+    returns (gathered rows, this rank's first row) -- so the kernels enqueued between issue and wait do not queue behind the
+    collective, nor behind a slower rank's half of it."""
+
+    def __init__(self, out: torch.Tensor, offset: int, work=None):
+        self.out, self.offset, self._work = out, offset, work
+
+    def wait(self) -> Tuple[torch.Tensor, int]:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self.out, self.offset
+
+
+def gather_rows_async(x_local: torch.Tensor, group=None) -> PendingGather:
+    """`gather_rows` issued with async_op=True: returns at once; the result is valid after `.wait()`."""
+    rank, world = world_info(group)
+    if world == 1:
+        return PendingGather(x_local, 0)
+    x_local = x_local.contiguous()
+    out = torch.empty((world * x_local.shape[0], x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
+    work = dist.all_gather_into_tensor(out, x_local, group=group, async_op=True)
+    return PendingGather(out, rank * x_local.shape[0], work)
+
+
+def average_loss(loss: torch.Tensor, group=None) -> torch.Tensor:
+    """Mean over ranks of a (device) loss scalar -- equal local batches, so this is the loss of the global batch.  The
+    reference all-reduces its loss sums once per epoch (scripts/train_contrast.py:468,514); this is the per-step form for
+    logging.  Returns a NEW tensor; `loss` is untouched."""
+    _, world = world_info(group)
+    out = loss.detach().clone()
+    if world == 1:
+        return out
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    out /= world
+    return out
+
+
 def segment_labels(r0: int, r1: int, offset: int, device, dtype=torch.int32) -> torch.Tensor:
     """Target columns of local rows r0..r1-1 in the gathered text matrix: the reference's
     `labels = arange(seg * size, (seg + 1) * size)` (scripts/train_contrast.py:367-371) shifted by the rank's offset
@@ -83,25 +122,38 @@ def sharded_forward_backward(*, text_fn: Callable[[], torch.Tensor],
                              segments: Sequence[Segment], global_negatives: bool, flat_g: Optional[torch.Tensor],
                              backward: bool = True, reduce: bool = True, group=None,
                              protein_fn: Optional[Callable[[], torch.Tensor]] = None,
-                             column_fn: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None) -> None:
+                             column_fn: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None,
+                             prefetch_fn: Optional[Callable[[int, int, int, int], None]] = None) -> None:
     """One micro-batch of the sharded step on this rank.
 
         t_local = text_fn()                              normalised text embeddings of the local rows (no grad)
-        t_all, offset = all-gather over ranks            (global_negatives; else the local block, offset 0)
+        all-gather over ranks, ISSUED ASYNCHRONOUSLY     (global_negatives; else the local block, offset 0)
+        prefetch_fn(0, r0, r1, T)                        optional: enqueue the first segment's encoder (it does not depend on
+                                                         the gathered text); the caller keeps the result for segment_fn
+        wait for the gather                              -> t_all, offset
         for every protein-side segment (r0, r1, T, w):   segment_fn(s, r0, r1, T, w, t_all, labels, offset)
             with labels = offset + arange(r0, r1)        -> loss rows + adapter gradients of that segment
         average the flat adapter gradients over ranks    (backward and reduce)
+
+    The encoder of the first segment (85 % of the step) thus runs while the text embeddings travel, and a rank that finishes
+    its text tower early starts encoding instead of waiting for the slowest rank's text tower.
 
     Column (text -> protein) term, optional: `protein_fn()` returns the normalised protein embeddings of ALL local rows
     (forward only); they are all-gathered too and `column_fn(p_all, t_all, offset)` prepares the global column
     log-sum-exps before the segments run."""
     t_local = text_fn()
-    t_all, offset = gather_rows(t_local, group) if global_negatives else (t_local, 0)
+    pending = gather_rows_async(t_local, group) if global_negatives else PendingGather(t_local, 0)
     if column_fn is not None:
-        p_local = protein_fn()
+        p_local = protein_fn()                          # every segment's forward: runs while the text gather is in flight
+        t_all, offset = pending.wait()
         p_all, p_off = gather_rows(p_local, group) if global_negatives else (p_local, 0)
         assert p_off == offset
         column_fn(p_all, t_all, offset)
+    else:
+        if prefetch_fn is not None and len(segments) > 0:
+            r0, r1, T, _ = segments[0]
+            prefetch_fn(0, r0, r1, T)
+        t_all, offset = pending.wait()
     dev = t_all.device
     for s, (r0, r1, T, weight) in enumerate(segments):
         segment_fn(s, r0, r1, T, weight, t_all, segment_labels(r0, r1, offset, dev), offset)

@@ -55,6 +55,7 @@ class OracleRank:
         n = sum(int(np.prod(self.W[k].shape)) for k in NAMES)
         self.flat_g = torch.zeros((n,), dtype=torch.float32)
         self.loss = 0.0
+        self.prefetched = 0
 
     def forward_backward(self, micro, accumulate, grad_scale, reduce):
         from p2t_hip import sharding
@@ -102,10 +103,15 @@ class OracleRank:
             grads = O.adapter_backward(self.W, keep, dad, prefix="adapter.")
             self.flat_g += torch.from_numpy(np.concatenate([grads[n].ravel() for n in NAMES]))
 
+        def prefetch_fn(s, r0, r1, T):          # the trainer's: first segment's encoder before the wait for the gathered text
+            self.prefetched += 1
+            seg_forward(s, r0, r1)
+
         sharding.sharded_forward_backward(text_fn=text_fn, segment_fn=segment_fn, segments=segments,
                                           global_negatives=self.global_negatives, flat_g=self.flat_g, backward=True,
                                           reduce=reduce, protein_fn=protein_fn if cw > 0 else None,
-                                          column_fn=column_fn if cw > 0 else None)
+                                          column_fn=column_fn if cw > 0 else None,
+                                          prefetch_fn=prefetch_fn if (cw == 0 and self.global_negatives) else None)
         self.loss = state["loss"]
         return self.loss
 
@@ -133,10 +139,13 @@ def _worker(rank, world, port, q, mode):
                 if micro == 0:                  # no exchange yet: the buffer holds this rank's own half-weighted gradients
                     local = r.flat_g.clone()
             out = (losses, r.flat_g.numpy().copy(), local.numpy())
+        elif mode.startswith("epoch"):
+            out = _epoch_worker(meta, rank, world, mode)
         else:
             r = OracleRank(meta, rank, world, global_negatives=(mode != "local"), column_weight=0.5 if mode == "column" else 0.0,
                            num_segments=2 if mode == "column" else 1)
             loss = r.forward_backward(0, False, 1.0, True)
+            assert r.prefetched == (1 if mode == "global" else 0)      # the encoder went out before the wait for the gather
             out = ([loss], r.flat_g.numpy().copy(), None)
         gathered = [None] * world
         dist.all_gather_object(gathered, out)
@@ -144,6 +153,96 @@ def _worker(rank, world, port, q, mode):
             q.put(gathered)
     finally:
         dist.destroy_process_group()
+
+
+class _HostStats:
+    """p2t_epoch_accumulate's arithmetic on host tensors (csrc/misc.hip epoch_accumulate_kernel): stands where the kernel is,
+    like the oracle stands where the tower kernels are -- the epoch logic around it is the product's loop.train_epoch."""
+
+    def __new__(cls):
+        from p2t_hip import loop
+
+        class HostStats(loop.EpochStats):
+            def __init__(self):
+                self.sums = torch.zeros(4)
+                self.flags = torch.tensor([0, -1, 0, 0], dtype=torch.int32)
+                self._reported = 0
+                self.fault = 0
+
+            def add(self, loss, grad_norm, batch_idx):
+                l = float(loss)
+                self.sums[0] += l
+                self.sums[1] += 1
+                if grad_norm is not None:
+                    self.sums[2] += float(grad_norm)
+                    self.sums[3] += 1
+                if not (l > 0.0) or l == float("inf"):
+                    if int(self.flags[0]) == 0:
+                        self.flags[1] = batch_idx
+                        self.flags[3] = int(np.float32(l).view(np.int32))
+                    self.flags[0] += 1
+                self.flags[2] |= self.fault
+        return HostStats()
+
+
+class _EpochTrainer:
+    """The attributes loop.train_epoch / eval_epoch use of a ContrastiveTrainer, over an OracleRank."""
+
+    def __init__(self, meta, rank, world, ga, poison_at=None):
+        self.r = OracleRank(meta, rank, world, True)
+        self.gradient_accumulation_steps, self._micro, self.step_count = ga, 0, 0
+        self.dev, self.group, self.schedule, self.hp, self.train_mode = "cpu", None, None, {"lr": 2e-4}, False
+        self.grad_norm = torch.zeros(1)
+        self.model = torch.nn.Identity()
+        self.poison_at, self.seen = poison_at, 0
+
+    def step(self, batch):
+        from p2t_hip import sharding
+        accumulate, grad_scale, reduce, do_step = sharding.micro_step_plan(self._micro, self.gradient_accumulation_steps)
+        loss = self.r.forward_backward(batch["micro"], accumulate, grad_scale, reduce)
+        if self.poison_at is not None and self.seen == self.poison_at:
+            loss = float("nan")
+        self.seen += 1
+        self._micro += 1
+        if do_step:
+            self.step_count += 1
+            self.grad_norm = self.r.flat_g.norm().reshape(1)
+            self._micro = 0
+        return torch.tensor([loss], dtype=torch.float32)
+
+    def evaluate(self, batch):
+        return torch.tensor([self.r.forward_backward(batch["micro"], False, 1.0, False)], dtype=torch.float32)
+
+
+def _epoch_worker(meta, rank, world, mode):
+    """loop.train_epoch / eval_epoch on two ranks: device sums -> ONE all-reduce -> the reference's epoch summary."""
+    from p2t_hip import loop
+    lines = []
+    batches = [{"micro": 0}, {"micro": 1}]
+    if mode == "epoch":
+        tr = _EpochTrainer(meta, rank, world, ga=2)
+        rec = loop.train_epoch(tr, batches, rank=rank, current_epoch=1, num_epochs=3, check_every=1, log=lines.append, stats=_HostStats())
+        ev = loop.eval_epoch(tr, batches, rank=rank, current_epoch=1, num_epochs=3, log=lines.append, stats=_HostStats())
+        return ([rec["train_loss"], ev["eval_loss"], rec["epoch_gradnorm"], rec["batches"], rec["optimizer_steps"]], np.zeros(1), lines)
+    if mode == "epoch_nan":             # rank 1's second batch is NaN: reported there, and the epoch aborts on EVERY rank
+        tr = _EpochTrainer(meta, rank, world, ga=1, poison_at=1 if rank == 1 else None)
+        try:
+            loop.train_epoch(tr, batches, rank=rank, check_every=1, log=lines.append, stats=_HostStats())
+            raised = False
+        except ValueError as e:
+            raised = "NaN detected in the training loss of the epoch" in str(e)
+        return ([float(raised)], np.zeros(1), lines)
+    if mode == "epoch_fault":           # the fault word set (here on both GPUs' stand-ins): the rank raises at its next check,
+        tr = _EpochTrainer(meta, rank, world, ga=1)        # BEFORE the epoch's all-reduce -- a faulted rank never reports a loss
+        st = _HostStats()
+        st.fault = 1
+        try:
+            loop.eval_epoch(tr, batches[:1], rank=rank, check_every=1, log=lines.append, stats=st)
+            raised = False
+        except loop.SplitKTimeout:
+            raised = True
+        return ([float(raised)], np.zeros(1), lines)
+    raise ValueError(mode)
 
 
 def _run(mode, world=2):
@@ -245,3 +344,27 @@ def test_sharding_helpers_single_process():
         sharding.micro_step_plan(2, 2)
     g = torch.ones(4)
     assert sharding.average_gradients(g) is g and g.tolist() == [1.0] * 4
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_epoch_sums_are_all_reduced_once_and_guards_fire():
+    """loop.train_epoch / eval_epoch (scripts/train_contrast.py:400-519) over two ranks: the epoch loss is the all-reduced sum
+    over ranks and batches / the all-reduced batch count (= the mean of the single-process segmented losses of the two
+    micro-batches), rank 0 prints the reference's summary lines; a NaN batch on ONE rank is reported there with its index and
+    aborts the epoch on BOTH (the reduced sum is NaN everywhere); a set fault word raises SplitKTimeout."""
+    meta = load_golden("tiny")["meta"]
+    refs = [_single_process(meta, micro=m, num_segments=2) for m in range(2)]
+    want = float(np.mean([float(r["loss"]) for r in refs]))
+    res = _run("epoch")
+    for r in res:
+        assert abs(r[0][0] - want) < 2e-5 and abs(r[0][1] - want) < 2e-5           # train and eval loss, identical on both ranks
+        assert r[0][3] == 4.0 and r[0][4] == 1.0                                    # 2 ranks x 2 batches; one optimizer step (GA = 2, local count)
+    assert any(line.startswith("[epoch=1/3, train_loss=") and "epoch_gradnorm=" in line for line in res[0][2])
+    assert any(line.startswith("[epoch=1/3, eval_loss=") for line in res[0][2])
+    assert not res[1][2]                                                            # only rank 0 prints the summaries
+    res = _run("epoch_nan")
+    assert res[0][0] == [1.0] and res[1][0] == [1.0]
+    assert not any("Impossible" in line for line in res[0][2])
+    assert any(line.startswith("Impossible batch_loss detected at batch 1: nan") for line in res[1][2])
+    res = _run("epoch_fault")
+    assert res[0][0] == [1.0] and res[1][0] == [1.0]

@@ -3,8 +3,9 @@
 * configs[1] (esm2_t12_35M + Llama-3.2-1B, bf16): the HIP path against the CPU oracle on the FULL models (12 + 16
   layers, head_dim 24 encoder, 128256-token vocabulary), a 4-pair ragged slice of the batch so the oracle finishes in
   seconds; both sides read the same weights (the GPU model's).
-* configs[2] (esm2_t36_3B + Llama-3.1-8B, bf16, 1024 residues): too large for the oracle, so size-independent properties
-  of the step: permutation equivariance, padding invariance, segment additivity, agreement of the bf16 MFMA pipeline with
+* configs[2] (esm2_t36_3B + Llama-3.1-8B, bf16, 1024 residues) and configs[4]'s one-GPU share (the same models, fp8 tower
+  GEMMs): two ragged pairs against the CPU oracle at full depth (~25 s of CPU per precision), then -- at batch sizes the oracle
+  cannot reach -- size-independent properties of the step: permutation equivariance, padding invariance, segment additivity, agreement of the bf16 MFMA pipeline with
   the exact fp32 pipeline on the same weights, and a falling loss under the fused optimizer step.
 """
 import os
@@ -76,6 +77,73 @@ def cfg3():
     yield dict(P=P, model=model, esm=esm, llama=llama, ad=ad, Tp=Tp, Tt=Tt, pid=pid, pmask=pmask, tid=tid, tmask=tmask)
     del model
     torch.cuda.empty_cache()
+
+
+def _cfg3_oracle_pairs(cfg3):
+    """Two ragged pairs at the benchmarked sizes: a full-length protein (1024 residues) beside a 411-residue one, a
+    full-length description (128 tokens) beside a 33-token one."""
+    Tp, Tt = cfg3["Tp"], cfg3["Tt"]
+    pid, pmask = synth.protein_batch(51, 2, Tp, [Tp, 411])
+    tid, tmask = synth.text_batch(51, 2, Tt, 128000, [Tt, 33], 128002, 128009)
+    return pid, pmask, tid, tmask
+
+
+_ORACLE = {}
+
+
+def _cfg3_oracle(cfg3, name, prec):
+    """O.contrastive_step on the two pairs with the GPU model's weights (each precision computed once per session: ~25 s)."""
+    if name not in _ORACLE:
+        from oracle import p2t_oracle as O
+        sys.path.insert(0, ROOT)
+        from bench import GpuWeights
+        pid, pmask, tid, tmask = _cfg3_oracle_pairs(cfg3)
+        _ORACLE[name] = O.contrastive_step(cfg3["esm"], cfg3["llama"], GpuWeights(cfg3["model"]), pid, pmask, tid, tmask,
+                                           layer=16, num_segments=1, prec=prec)
+    return _ORACLE[name]
+
+
+def _step_outputs(P, model, b):
+    with torch.no_grad():
+        p = P.l2_normalize(P.get_sequence_embeddings(model, b["protein_input_ids"], b["protein_attention_mask"]))
+        t = P.l2_normalize(P.get_description_embeddings(model, b["description_input_ids"], b["description_attention_mask"], 16))
+        loss = float(P.BatchInfoNCELoss()(p, t))
+    return to_np(p), to_np(t), loss
+
+
+def test_cfg3_full_models_vs_cpu_oracle(cfg3):
+    """BASELINE.json configs[2] -- the configuration bench.py times -- against the CPU oracle (the restatement of
+    scripts/train_contrast.py:284-310,345-379 that tests/test_oracle_golden.py pins on the reference's own outputs): the full
+    36-layer esm2_t36_3B + 16 layers of Llama-3.1-8B, same weights on both sides (the GPU model's), pooled embeddings and loss.
+    Once against the oracle that rounds where the HIP path stores bf16, once against the fp32 oracle (= the reference's CPU
+    arithmetic)."""
+    from oracle import p2t_oracle as O
+    P, model = cfg3["P"], cfg3["model"]
+    pid, pmask, tid, tmask = _cfg3_oracle_pairs(cfg3)
+    p, t, loss = _step_outputs(P, model, _batch(pid, pmask, tid, tmask))
+    for name, prec, caps in (("bf16oracle", O.BF16, (1e-2, 1e-2)), ("fp32oracle", O.FP32, (1e-2, 3e-2))):
+        ref = _cfg3_oracle(cfg3, name, prec)
+        observe(f"cfg3.bf16_vs_{name}.text", rel(t, ref["text"]), caps[0])
+        observe(f"cfg3.bf16_vs_{name}.protein", rel(p, ref["protein"]), caps[0])
+        observe(f"cfg3.bf16_vs_{name}.loss", abs(loss - float(ref["loss"])) / max(1.0, abs(float(ref["loss"]))), caps[1], "abs/max(1,|ref|)")
+
+
+def test_cfg5_fp8_full_models_vs_cpu_oracle(cfg3):
+    """BASELINE.json configs[4] (one GPU's share): the cfg3 models with fp8 tower GEMMs against the oracle that quantises the
+    same operands the same way (O.FP8) and against the fp32 oracle."""
+    from oracle import p2t_oracle as O
+    P, model = cfg3["P"], cfg3["model"]
+    pid, pmask, tid, tmask = _cfg3_oracle_pairs(cfg3)
+    try:
+        model.set_gemm_dtype("fp8")
+        p, t, loss = _step_outputs(P, model, _batch(pid, pmask, tid, tmask))
+    finally:
+        model.set_gemm_dtype("model")
+    for name, prec, caps in (("fp8oracle", O.FP8, (1e-1, 1e-1)), ("fp32oracle", O.FP32, (2e-1, 2e-1))):
+        ref = _cfg3_oracle(cfg3, name, prec)
+        observe(f"cfg5.fp8_vs_{name}.text", rel(t, ref["text"]), caps[0])
+        observe(f"cfg5.fp8_vs_{name}.protein", rel(p, ref["protein"]), caps[0])
+        observe(f"cfg5.fp8_vs_{name}.loss", abs(loss - float(ref["loss"])) / max(1.0, abs(float(ref["loss"]))), caps[1], "abs/max(1,|ref|)")
 
 
 def test_cfg3_permutation_equivariance_and_padding_invariance(cfg3):

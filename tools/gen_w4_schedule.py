@@ -79,19 +79,18 @@ def emit(sc):
 
 
 def main():
-    parts, counts = [], []
+    # order 1 is the product's (+0.5 % in-step over order 0, profiles/r02_*); order 0 is compiled into the lab build only
+    bodies, counts = {}, {}
     for k in sorted(SCHEDULES):
-        body, before = emit(SCHEDULES[k])
-        counts.append(before)
-        parts.append(("        if constexpr (SCHED == %d) {\n" % k if k == 0 else "        } else if constexpr (SCHED == %d) {\n" % k) + body + "\n")
-    text = "".join(parts) + "        }\n"
+        bodies[k], counts[k] = emit(SCHEDULES[k])
+    text = ("        if constexpr (SCHED == 1) {\n" + bodies[1] + "\n        }\n#ifdef P2T_LAB\n        else if constexpr (SCHED == 0) {\n"
+            + bodies[0] + "\n        }\n#endif\n")
     with open(PATH) as f:
         s = f.read()
     a = s.index("        // GENERATED (tools/gen_w4_schedule.py) BEGIN")
     b = s.index("        // GENERATED END")
     s = s[:a] + "        // GENERATED (tools/gen_w4_schedule.py) BEGIN\n" + text + s[b:]
-    s = re.sub(r"constexpr int kIssuedBeforeWait = [^;]*;", "constexpr int kIssuedBeforeWait = " + " : ".join(
-        [f"SCHED == {k} ? {c}" for k, c in zip(sorted(SCHEDULES), counts)][:-1] + [str(counts[-1])]) + ";", s)
+    s = re.sub(r"constexpr int kIssuedBeforeWait = [^;]*;", f"constexpr int kIssuedBeforeWait = SCHED == 0 ? {counts[0]} : {counts[1]};", s)
     with open(PATH, "w") as f:
         f.write(s)
     print("pieces before the wait:", counts)
