@@ -180,10 +180,13 @@ int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos
 /* Attention.  q [B, nh, T, dp], k and v [B, nkv, T, dp], all `dtype`, row-major (the MFMA kernel transposes V with
  * ds_read_b64_tr_b16).  key_mask u8 [B, T] (1 = valid), kv_info i32 [2B] from p2t_mask_prepare.
  * softmax(scale * q k^T + mask) v -> out [B*T, ld_out] `dtype`, head h in columns h*d..h*d+d-1; columns nh*d up to the
- * next multiple of 64 (the o-proj K padding) zeroed.  causal: also require key <= query. */
+ * next multiple of 64 (the o-proj K padding) zeroed.  causal: also require key <= query.
+ * log2_scores != 0: q was stored pre-multiplied by scale * log2(e) (what the towers do for bf16 models, through the q_scale
+ * of p2t_gemm_qkv_rope / p2t_qkv_post: q is rounded to bf16 once either way), so q k^T is the base-2 exponent itself:
+ * `scale` is ignored, the result is softmax_2(q k^T + mask) v = the same attention, one multiply-add less per score. */
 int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
                   void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
-                  int dtype, int use_mfma, p2t_stream stream);
+                  int dtype, int use_mfma, int log2_scores, p2t_stream stream);
 
 /* ---------------------------------------------------------------- ESM2 encoder */
 typedef struct {

@@ -122,10 +122,17 @@ class Precision:
     def g(self, x):           # "quantise a tower-GEMM operand" (rows of a 2-D array)
         return quant_rows_e4m3(x)[0] if self.kind == "fp8" else x
 
+    def qs(self, x, c):       # the query operand of attention: the HIP bf16 path stores q * c (c = softmax scale * log2 e folded
+        if self.kind == "f32":    # into q where it is written, csrc/towers.hip) and rounds THAT to bf16; same value, other rounding points
+            return x
+        c = F32(c)
+        return (_bf16(x * c) / c).astype(F32)
+
     def a(self, x):           # a norm output feeding a projection: bf16 storage, or straight to fp8 (no bf16 in between)
         return x if self.kind == "fp8" else self.q(x)
 
 
+LOG2E = 1.4426950408889634
 FP32 = Precision("f32")
 BF16 = Precision("bf16")
 FP8 = Precision("fp8")
@@ -267,7 +274,7 @@ def esm2_layer(spec, W, i, x, key_bias, cos, sin, prec: Precision = FP32, prefix
     q = q * F32(d ** -0.5)
     q = q * cos + rotate_half(q) * sin                                    # ESM:74-79 (fp32)
     k = k * cos + rotate_half(k) * sin
-    q, k, v = q_(q), q_(k), q_(v)
+    q, k, v = prec.qs(q, LOG2E), q_(k), q_(v)
     o = g_(q_(attention_heads(q, k, v, key_bias, 1.0, prec).reshape(B * T, H)))     # ESM:310-317, scale 1.0
     x = x + lin("attention.output.dense", o).reshape(B, T, H)               # ESM:399-409
     h = prec.a(layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], spec.layer_norm_eps))
@@ -375,7 +382,7 @@ def llama_layer(spec, W, i, x, bias, cos, sin, prec: Precision = FP32, prefix=""
         v = q_(v)
     q = q * cos + rotate_half(q) * sin
     k = k * cos + rotate_half(k) * sin
-    q, k, v = q_(q), q_(k), q_(v)
+    q, k, v = prec.qs(q, LOG2E * d ** -0.5), q_(k), q_(v)
     o = g_(q_(attention_heads(q, k, v, bias, d ** -0.5, prec).reshape(B * T, nh * d)))
     x = x + (o @ wq("self_attn.o_proj").T).reshape(B, T, H)
     h = g_(prec.a(rms_norm(x, W[p + "post_attention_layernorm.weight"], spec.rms_norm_eps)).reshape(B * T, H))
@@ -573,6 +580,127 @@ def contrastive_step(esm_spec, llama_spec, W, prot_ids, prot_mask, text_ids, tex
         dad = readout_backward(keep["adapter_out"], keep["rmask"], readout, dpooled)
         out["grads"] = adapter_backward(W, keep, dad, prec, prefix="adapter.")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# stage 2 (SFT): LM loss through the frozen decoder and its gradient back to the adapter
+# (REF models/modeling_esm2llama_instruct.py:108-139,195-215; scripts/train_instruct.py:192-213 `loss.backward()`).
+# fp32 only; manual backward (what torch autograd does through HF LlamaForCausalLM, restated op by op).
+# ---------------------------------------------------------------------------------------------
+def rms_norm_backward(x, w, eps, dy):
+    """y = x * rsqrt(mean(x^2) + eps) * w (LLAMA:62-67)  ->  dx."""
+    x = x.astype(F32, copy=False)
+    r = (F32(1.0) / np.sqrt((x * x).mean(-1, keepdims=True, dtype=F32) + F32(eps))).astype(F32)
+    gy = (dy * w).astype(F32)
+    return (r * gy - x * (r * r * r) * (gy * x).mean(-1, keepdims=True, dtype=F32)).astype(F32)
+
+
+def rotate_half_transposed(y):
+    """Transpose of rotate_half: rotate_half(x) = [-x2, x1]  ->  R^T y = [y2, -y1]."""
+    h = y.shape[-1] // 2
+    return np.concatenate([y[..., h:], -y[..., :h]], axis=-1)
+
+
+def llama_lm_loss_and_grad(spec, W, inputs_embeds, mask, labels, prefix="llama_decoder."):
+    """LlamaForCausalLM(inputs_embeds, attention_mask, labels): all layers -> final RMSNorm -> LM head -> shifted cross-entropy
+    (ForCausalLMLoss: logits[:, :-1] against labels[:, 1:], ignore_index -100, mean over the counted positions), and the gradient
+    of that loss with respect to inputs_embeds.  -> (loss, d_inputs_embeds [B, T, H], logits [B, T, V])."""
+    x = np.ascontiguousarray(inputs_embeds, dtype=F32)
+    mask = np.asarray(mask); labels = np.asarray(labels)
+    B, T, H = x.shape
+    L, nh, nkv, d = spec.num_hidden_layers, spec.num_attention_heads, spec.num_key_value_heads, spec.head_dim
+    rep, scale = nh // nkv, F32(d ** -0.5)
+    allowed = np.tril(np.ones((T, T), dtype=bool))[None, None] & (mask[:, None, None, :] != 0)
+    bias = np.where(allowed, F32(0.0), NEG).astype(F32)
+    cos, sin = rope_cos_sin(llama_inv_freq(spec), np.arange(T))
+    saved = []
+    for i in range(L):
+        p = f"{prefix}model.layers.{i}."
+        w1, w2 = W[p + "input_layernorm.weight"], W[p + "post_attention_layernorm.weight"]
+        Wq, Wk, Wv, Wo = (W[p + f"self_attn.{n}_proj.weight"] for n in "qkvo")
+        Wg, Wu, Wd = (W[p + f"mlp.{n}_proj.weight"] for n in ("gate", "up", "down"))
+        h = rms_norm(x, w1, spec.rms_norm_eps).reshape(B * T, H)
+        q = (h @ Wq.T).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+        k = (h @ Wk.T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+        v = (h @ Wv.T).reshape(B, T, nkv, d).transpose(0, 2, 1, 3)
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        kr, vr = np.repeat(k, rep, axis=1), np.repeat(v, rep, axis=1)               # repeat_kv (LLAMA:181-188)
+        P = softmax_rows(np.einsum("bhid,bhjd->bhij", q, kr) * scale + bias)
+        o = np.einsum("bhij,bhjd->bhid", P, vr).transpose(0, 2, 1, 3).reshape(B * T, nh * d)
+        x1 = x + (o @ Wo.T).reshape(B, T, H)
+        h2 = rms_norm(x1, w2, spec.rms_norm_eps).reshape(B * T, H)
+        g, u = h2 @ Wg.T, h2 @ Wu.T
+        sg = (F32(1.0) / (F32(1.0) + np.exp(-g, dtype=F32))).astype(F32)
+        x2 = x1 + ((g * sg * u) @ Wd.T).reshape(B, T, H)
+        saved.append((x, q, kr, vr, P, x1, g, u, sg))
+        x = x2.astype(F32)
+    wn = W[prefix + "model.norm.weight"]
+    Wlm = W[prefix + ("model.embed_tokens.weight" if spec.tie_word_embeddings else "lm_head.weight")]
+    if not isinstance(Wlm, np.ndarray):                   # a row-gather table (oracle/weights.py): the tied LM head needs every row
+        Wlm = Wlm[np.arange(spec.vocab_size)]
+    logits = (rms_norm(x, wn, spec.rms_norm_eps).reshape(B * T, H) @ Wlm.T).reshape(B, T, -1).astype(F32)
+    # ForCausalLMLoss (transformers/loss/loss_utils.py): shift, flatten, F.cross_entropy(ignore_index=-100, reduction mean)
+    tgt = np.full((B, T), -100, dtype=np.int64)
+    tgt[:, :-1] = labels[:, 1:]
+    counted = tgt != -100
+    n = max(int(counted.sum()), 1)
+    z = logits.astype(np.float64)
+    z = z - z.max(-1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(-1, keepdims=True))
+    bi, ti = np.nonzero(counted)
+    loss = F32(-logp[bi, ti, tgt[bi, ti]].sum() / n)
+    dlogits = np.exp(logp)
+    dlogits[bi, ti, tgt[bi, ti]] -= 1.0
+    dlogits = (dlogits * counted[..., None] / n).astype(F32)
+    # ---- backward
+    dx = rms_norm_backward(x, wn, spec.rms_norm_eps, (dlogits.reshape(B * T, -1) @ Wlm).reshape(B, T, H))
+    for i in reversed(range(L)):
+        p = f"{prefix}model.layers.{i}."
+        w1, w2 = W[p + "input_layernorm.weight"], W[p + "post_attention_layernorm.weight"]
+        Wq, Wk, Wv, Wo = (W[p + f"self_attn.{n}_proj.weight"] for n in "qkvo")
+        Wg, Wu, Wd = (W[p + f"mlp.{n}_proj.weight"] for n in ("gate", "up", "down"))
+        x0, q, kr, vr, P, x1, g, u, sg = saved[i]
+        da = dx.reshape(B * T, H) @ Wd
+        dg = da * u * (sg * (F32(1.0) + g * (F32(1.0) - sg)))
+        du = da * (g * sg)
+        dx1 = dx + rms_norm_backward(x1, w2, spec.rms_norm_eps, (dg @ Wg + du @ Wu).reshape(B, T, H))
+        do = (dx1.reshape(B * T, H) @ Wo).reshape(B, T, nh, d).transpose(0, 2, 1, 3)
+        dvr = np.einsum("bhij,bhid->bhjd", P, do)
+        dP = np.einsum("bhid,bhjd->bhij", do, vr)
+        dS = P * (dP - (dP * P).sum(-1, keepdims=True, dtype=F32))              # softmax backward; (dP * P).sum = rowsum(dO * O)
+        dq = np.einsum("bhij,bhjd->bhid", dS, kr) * scale
+        dkr = np.einsum("bhij,bhid->bhjd", dS, q) * scale
+        dk = dkr.reshape(B, nkv, rep, T, d).sum(2)                                # the repeated heads share one key / value head
+        dv = dvr.reshape(B, nkv, rep, T, d).sum(2)
+        dq = dq * cos + rotate_half_transposed(dq * sin)
+        dk = dk * cos + rotate_half_transposed(dk * sin)
+        flat = lambda t, heads: t.transpose(0, 2, 1, 3).reshape(B * T, heads * d)
+        dh = flat(dq, nh) @ Wq + flat(dk, nkv) @ Wk + flat(dv, nkv) @ Wv
+        dx = (dx1 + rms_norm_backward(x0, w1, spec.rms_norm_eps, dh.reshape(B, T, H))).astype(F32)
+    return loss, dx, logits
+
+
+def sft_decoder_inputs(llama_spec, W, input_ids, adapter_out, prot_mask, placeholder_id, prefix="llama_decoder."):
+    """prepare_decoder_inputs (REF models/modeling_esm2llama_instruct.py:108-139): token embeddings with the placeholder positions
+    replaced by the adapter rows under the protein mask, both in row-major order."""
+    emb = W[prefix + "model.embed_tokens.weight"][np.asarray(input_ids)].astype(F32)
+    emb[np.asarray(input_ids) == placeholder_id] = adapter_out[np.asarray(prot_mask) != 0]
+    return emb
+
+
+def sft_step(esm_spec, llama_spec, W, prot_ids, prot_mask, input_ids, attention_mask, labels, placeholder_id):
+    """One stage-2 step with the towers frozen and the adapter trainable (REF scripts/train_instruct.py:192-213 without LoRA):
+    -> dict(loss, logits, inputs_embeds, d_inputs_embeds, grads of adapter.{fc1,fc2}.{weight,bias})."""
+    keep = {}
+    enc = esm2_forward(esm_spec, W, prot_ids, prot_mask, FP32, prefix="esm_encoder.")
+    ad = adapter_forward(W, enc, FP32, prefix="adapter.", keep=keep)
+    emb = sft_decoder_inputs(llama_spec, W, input_ids, ad, prot_mask, placeholder_id)
+    loss, demb, logits = llama_lm_loss_and_grad(llama_spec, W, emb, attention_mask, labels)
+    dad = np.zeros_like(ad)
+    dad[np.asarray(prot_mask) != 0] = demb[np.asarray(input_ids) == placeholder_id]      # backward of the boolean-mask assignment
+    return {"loss": loss, "logits": logits, "inputs_embeds": emb, "d_inputs_embeds": demb, "d_adapter_out": dad,
+            "grads": adapter_backward(W, keep, dad, FP32, prefix="adapter.")}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -44,10 +44,11 @@ class _RowTable:
         return rows[inv].reshape(*ids.shape, self.shape[1])
 
 
-def model_weights(esm, llama, ad, seed=0, cache=True):
+def model_weights(esm, llama, ad, seed=0, cache=True, lm_head=False):
+    """lm_head=True adds `llama_decoder.lm_head.weight` (untied decoders; the stage-2 tests need the LM head)."""
     import itertools
     return LazyWeights(itertools.chain(specs.esm_tensors(esm, "esm_encoder."),
                                        specs.adapter_tensors(ad, "adapter."),
-                                       specs.llama_tensors(llama, "llama_decoder.", lm_head=False)), seed, cache)
+                                       specs.llama_tensors(llama, "llama_decoder.", lm_head=lm_head)), seed, cache)
 
 

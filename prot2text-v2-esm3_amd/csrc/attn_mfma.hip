@@ -39,8 +39,16 @@ __device__ __forceinline__ int swz_g(int row) {
     return ((row & 3) << 2) | ((row >> 2) & 3);
 }
 
-template <int DP>
-__global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+// L2S ("log2 scores"): the caller stored q pre-multiplied by scale * log2(e) (the towers fold it into the q-scale of the QKV
+// epilogue, where q is rounded to bf16 once either way), so K . Q^T already IS the exponent in base 2.  The running reference m
+// of the exponentials is then folded into the QK^T MFMA as its accumulator INPUT (16 registers holding -m, rewritten only when
+// the lazy rescale moves m), and the softmax per score shrinks from fma + exp2 + add to exp2 + add: the vector pipe, not the matrix
+// pipe, bounds this kernel.
+template <int DP, bool L2S>
+// dp = 64: three waves per SIMD (three 48 KiB blocks per CU); the L2S form needs 16 registers more for -m and is held to that
+// budget (168 registers: two scalar-like values per step reload from scratch) -- at two waves per SIMD it measured 9 % slower
+// (profiles/r03_attn_ab.log)
+__global__ void __launch_bounds__(256, DP == 64 ? 3 : 2) attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                         const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out,
                                                         int64_t ld_out, int B, int seq, int nh, int nkv, int d,
@@ -164,6 +172,7 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    f32x16 negm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // L2S: -m_run on every register (0 while m_run = -inf)
 
     // One 64-key step on LDS buffer BUF (a compile-time constant: every ds_read address is then a per-lane VGPR
     // plus an immediate, no per-read address arithmetic on the VALU, which is the busier pipe in this kernel).
@@ -179,14 +188,14 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
         const char* sb = smem + BUF * STAGE;
         const int kb = it * 64;
 
-        // S^T tiles: rows = keys (permuted), cols = queries
+        // S^T tiles: rows = keys (permuted), cols = queries.  L2S: the accumulator starts at -m_run (0 before the first visible key)
         f32x16 st[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int kk = 0; kk < DK; ++kk) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off[t][kk]);
-                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : st[t], 0, 0, 0);
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? (L2S ? negm : zero16) : st[t], 0, 0, 0);
             }
         }
         // Masking only where a key of this 64-key step can be hidden from a query of this wave (tail of the
@@ -226,28 +235,59 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
         // harmless in fp32 / bf16, and the 32 accumulator multiplies + the alpha exponential are skipped (wave-uniform
         // branch).  The result is unchanged up to rounding: numerator and denominator carry the same reference.
         constexpr float kSlack = 8.0f;
-        const bool grow = mloc != -INFINITY && (m_run == -INFINITY || (mloc - m_run) * scale_log2e > kSlack);
-        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
-            const float m_new = fmaxf(m_run, mloc);                  // running reference of the RAW scores
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;   // fully masked so far: p = exp2(-inf) = 0
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2e);   // m_run = -inf -> 0
-            l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
-            m_run = m_new;
-        }
-        const float mc = (m_run == -INFINITY ? 0.f : m_run) * scale_log2e;
         float lsum = 0.f;
+        if constexpr (L2S) {
+            // st and mloc are RELATIVE to m_run (absolute while m_run = -inf: negm = 0), in log2 units
+            const bool first = m_run == -INFINITY;
+            const bool grow = mloc != -INFINITY && (first || mloc > kSlack);
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                const float delta = mloc == -INFINITY ? 0.f : (first ? mloc : fmaxf(mloc, 0.f));     // m_new - (first ? 0 : m_run)
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);                    // first: l_run = 0 and ot = 0 anyway
+                l_run *= alpha;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], scale_log2e, -mc));   // exp(scale * (s - m))
-                st[t][r] = p;
-                lsum += p;
+                    for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[t][r] -= delta;
+                if (mloc != -INFINITY || !first) m_run = (first ? 0.f : m_run) + delta;
+                const float nm = m_run == -INFINITY ? 0.f : -m_run;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = nm;
             }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(st[t][r]);                              // exp(scale * (s - m))
+                    st[t][r] = p;
+                    lsum += p;
+                }
+        } else {
+            const bool grow = mloc != -INFINITY && (m_run == -INFINITY || (mloc - m_run) * scale_log2e > kSlack);
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                const float m_new = fmaxf(m_run, mloc);                  // running reference of the RAW scores
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;   // fully masked so far: p = exp2(-inf) = 0
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2e);   // m_run = -inf -> 0
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = (m_run == -INFINITY ? 0.f : m_run) * scale_log2e;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], scale_log2e, -mc));   // exp(scale * (s - m))
+                    st[t][r] = p;
+                    lsum += p;
+                }
+        }
         lsum += __shfl_xor(lsum, 32, 64);
         l_run += lsum;
         // O^T += V^T . P^T
@@ -301,18 +341,22 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16_t* __restrict
 
 int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
                      void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
-                     hipStream_t s) {
+                     int log2_scores, hipStream_t s) {
     P2T_REQUIRE(d % 4 == 0 && (dp == 32 || dp == 64 || dp == 128) && d <= dp && nh % nkv == 0 && (nh * d) % 4 == 0 && ld_out % 4 == 0,
                 "attention(mfma): unsupported shape d=%d dp=%d heads %d/%d", d, dp, nh, nkv);
     const dim3 grid((unsigned)(ceil_div(T, 128) * nh * B));
     const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
     const float sl = scale * 1.4426950408889634f;
-#define P2T_ATTN(DPV)                                                                                              \
-    attn_mfma_kernel<DPV><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, \
-                                               (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols)
-    if (dp == 32) P2T_ATTN(32);
-    else if (dp == 64) P2T_ATTN(64);
-    else P2T_ATTN(128);
+#define P2T_ATTN(DPV)                                                                                                        \
+    if (log2_scores)                                                                                                         \
+        attn_mfma_kernel<DPV, true><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, \
+                                                         (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols);      \
+    else                                                                                                                     \
+        attn_mfma_kernel<DPV, false><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, \
+                                                          (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols)
+    if (dp == 32) { P2T_ATTN(32); }
+    else if (dp == 64) { P2T_ATTN(64); }
+    else { P2T_ATTN(128); }
 #undef P2T_ATTN
     P2T_LAUNCH_CHECK();
     return P2T_OK;

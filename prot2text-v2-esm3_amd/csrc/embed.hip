@@ -180,7 +180,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) qk_norm_rope_kernel(const T* __restrict__ qkv, int64_t ldq, const float* __restrict__ cs,
                                                            const float* __restrict__ qw, const float* __restrict__ kw, float eps,
                                                            T* __restrict__ q, T* __restrict__ k, T* __restrict__ v, int64_t rows, int seq,
-                                                           int nh, int nkv, int d, int dp) {
+                                                           int nh, int nkv, int d, int dp, float q_scale) {
     const int lane = threadIdx.x & 63, heads = nh + 2 * nkv, half = d / 2;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -200,8 +200,9 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(const T* __restrict__
         if (lane < half) {
             const float a1 = w[lane] * (x1 * rstd), a2 = w[lane + half] * (x2 * rstd);
             const float c = cs[(int64_t)t * d + lane], s = cs[(int64_t)t * d + half + lane];
-            dst[lane] = from_f32<T>(a1 * c - a2 * s);
-            dst[lane + half] = from_f32<T>(a2 * c + a1 * s);
+            const float qs = is_q ? q_scale : 1.0f;              // (the towers fold the softmax scale into q: kernels.h attention())
+            dst[lane] = from_f32<T>((a1 * c - a2 * s) * qs);
+            dst[lane + half] = from_f32<T>((a2 * c + a1 * s) * qs);
         }
     } else {
         dst = v + (((int64_t)b * nkv + (hh - nh - nkv)) * seq + t) * dp;
@@ -211,16 +212,16 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(const T* __restrict__
 }
 
 int launch_qk_norm_rope(const void* qkv, int64_t ldq, const float* cs, const float* q_norm_w, const float* k_norm_w, float eps, void* q,
-                        void* k, void* v, int B, int T, int nh, int nkv, int d, int dp, int dtype, hipStream_t s) {
+                        void* k, void* v, int B, int T, int nh, int nkv, int d, int dp, float q_scale, int dtype, hipStream_t s) {
     P2T_REQUIRE(d % 2 == 0 && d <= 128 && dp >= d && dp <= 128 && q_norm_w && k_norm_w, "qk_norm_rope: head_dim %d (padded %d) unsupported", d, dp);
     const int64_t rows = (int64_t)B * T * (nh + 2 * nkv);
     const dim3 grid((unsigned)ceil_div(rows, 4));
     if (dtype == P2T_BF16)
         qk_norm_rope_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)qkv, ldq, cs, q_norm_w, k_norm_w, eps, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v,
-                                                          rows, T, nh, nkv, d, dp);
+                                                          rows, T, nh, nkv, d, dp, q_scale);
     else
         qk_norm_rope_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, ldq, cs, q_norm_w, k_norm_w, eps, (float*)q, (float*)k, (float*)v, rows,
-                                                         T, nh, nkv, d, dp);
+                                                         T, nh, nkv, d, dp, q_scale);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

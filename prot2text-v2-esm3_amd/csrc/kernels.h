@@ -29,7 +29,7 @@ int launch_qkv_post(const void* qkv, int64_t ldq, const float* cs, void* q, void
                     int d, int dp, float q_scale, int dtype, hipStream_t s);
 
 int launch_qk_norm_rope(const void* qkv, int64_t ldq, const float* cs, const float* q_norm_w, const float* k_norm_w, float eps, void* q,
-                        void* k, void* v, int B, int T, int nh, int nkv, int d, int dp, int dtype, hipStream_t s);
+                        void* k, void* v, int B, int T, int nh, int nkv, int d, int dp, float q_scale, int dtype, hipStream_t s);
 
 int launch_gemm_simple(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int N, int K, int n_cover, int dtype,
                        int out_dtype, int epilogue, const EpiParams& ep, hipStream_t s);
@@ -72,10 +72,13 @@ int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_
                        int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype,
                        hipStream_t s);
 int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
-                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, hipStream_t s);
+                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int log2_scores, hipStream_t s);
+// log2_scores: q was stored pre-multiplied by scale * log2(e) (kLog2e below), so q k^T is already the base-2 exponent: `scale` is
+// ignored and p = exp2(s - m).  The towers do this for bf16 models (one multiply + add less per score in the MFMA kernel).
 int attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
               int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype, int use_mfma,
-              hipStream_t s);
+              int log2_scores, hipStream_t s);
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 // adapter tail helpers (adapter.hip)
 int launch_adapter_dz2(const void* g2, const void* z2, const float* inv_norm, const float* dy, void* dz2, int64_t ld, int64_t M,

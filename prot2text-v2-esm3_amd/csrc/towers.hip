@@ -129,7 +129,10 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
         inv_freq = b.inv_freq;
     }
     P2T_TRY(launch_rope_table(inv_freq, T, d / 2, b.cs, s));
-    const float q_scale = 1.0f / sqrtf((float)d);           // ESM scales q before rotary; SDPA scale is 1.0
+    // ESM scales q before rotary; SDPA scale is 1.0.  bf16 models: log2(e) rides along, so the attention kernel's exponent is
+    // q k^T itself (kernels.h attention(): log2_scores) -- q is rounded to bf16 once either way
+    const int l2s = dt == P2T_BF16;
+    const float q_scale = (l2s ? kLog2e : 1.0f) / sqrtf((float)d);
     P2T_CHECK_HIP(hipMemsetAsync(b.fix, 0, gemm_fix_header_bytes(), s));      // split-K tail flags; epochs below are unique
     unsigned epoch = 0;
     auto with_fix = [&](GemmArgs& g) { g.fix_ws = b.fix; g.fix_bytes = gemm_fix_workspace_bytes(); g.fix_epoch = ++epoch; };
@@ -157,7 +160,7 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
             P2T_TRY(gemm_nt(g1, s));
             P2T_TRY(launch_qkv_post(b.qkv, 3 * H, b.cs, b.q, b.k, b.v, B, T, nh, nh, d, dp, q_scale, dt, s));
         }
-        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, s));
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, l2s, s));
         P2T_TRY(launch_quant_rows(b.ao, dt, Hp, M, H, b.aoq, Hq, b.aos, s));
         GemmArgs g2 = fp8(b.aoq, Hq, b.aos, L.o_w, L.o_ws, L.o_b, b.x, H, H, Hq, P2T_F32, P2T_EPI_RESID);
         P2T_TRY(gemm_nt(g2, s));
@@ -193,7 +196,7 @@ extern "C" int p2t_esm2_forward(const p2t_esm2_config* c, const p2t_esm2_weights
             P2T_TRY(gemm_nt(g1, s));
             P2T_TRY(launch_qkv_post(b.qkv, 3 * H, b.cs, b.q, b.k, b.v, B, T, nh, nh, d, dp, q_scale, dt, s));
         }
-        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, s));
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, Hp, B, T, nh, nh, d, dp, 1.0f, 0, dt, -1, l2s, s));
         GemmArgs g2{b.ao, Hp, L.o_w, Hp, L.o_b, b.x, H, nullptr, M, H, Hp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         with_fix(g2);
         P2T_TRY(gemm_nt(g2, s));
@@ -249,6 +252,10 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
     }
     P2T_TRY(launch_rope_table(inv_freq, T, d / 2, b.cs, s));
     const float scale = 1.0f / sqrtf((float)d);
+    // bf16 models: the softmax scale and log2(e) are folded into q where it is written (rotation is linear), and the attention
+    // kernel's exponent is q k^T itself (kernels.h attention(): log2_scores)
+    const int l2s = dt == P2T_BF16;
+    const float q_fold = l2s ? scale * kLog2e : 1.0f;
     P2T_CHECK_HIP(hipMemsetAsync(b.fix, 0, gemm_fix_header_bytes(), s));      // split-K flags; epochs below are unique
     unsigned epoch = 0;
     auto with_fix = [&](GemmArgs& g) { g.fix_ws = b.fix; g.fix_bytes = gemm_fix_workspace_bytes(); g.fix_epoch = ++epoch; };
@@ -269,18 +276,18 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
             GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, b.qkv, NQKV, NQKV, Hq, dt, P2T_EPI_STORE);
             g1.n_zero = (int)NQKV;
             P2T_TRY(gemm_nt(g1, s));
-            P2T_TRY(launch_qk_norm_rope(b.qkv, NQKV, b.cs, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, b.q, b.k, b.v, B, T, nh, nkv, d, dp, dt, s));
+            P2T_TRY(launch_qk_norm_rope(b.qkv, NQKV, b.cs, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         } else if (d == 64 || d == 128) {
             GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, nullptr, 0, NQKV, Hq, dt, P2T_EPI_QKV_ROPE);
-            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f; g1.head_dim = d;
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = q_fold; g1.head_dim = d;
             P2T_TRY(gemm_nt(g1, s));
         } else {
             GemmArgs g1 = fp8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, b.qkv, NQKV, NQKV, Hq, dt, P2T_EPI_STORE);
             g1.n_zero = (int)NQKV;
             P2T_TRY(gemm_nt(g1, s));
-            P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, 1.0f, dt, s));
+            P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         }
-        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, s));
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, l2s, s));
         P2T_TRY(launch_quant_rows(b.ao, dt, QO, M, (int64_t)nh * d, b.aoq, QOq, b.aos, s));
         GemmArgs g2 = fp8(b.aoq, QOq, b.aos, L.o_w, L.o_ws, b.x, H, H, QOq, P2T_F32, P2T_EPI_RESID);
         P2T_TRY(gemm_nt(g2, s));
@@ -298,18 +305,18 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
         if (L.q_norm_w) {          // Qwen3: projection -> per-head RMSNorm -> rotation (not fusable: the norm spans the head)
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
             P2T_TRY(gemm_nt(g1, s));
-            P2T_TRY(launch_qk_norm_rope(b.qkv, NQKV, b.cs, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, b.q, b.k, b.v, B, T, nh, nkv, d, dp, dt, s));
+            P2T_TRY(launch_qk_norm_rope(b.qkv, NQKV, b.cs, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         } else if (d == 64 || d == 128) {
             // bias-free QKV projection + rotary + head split in the GEMM epilogue (d = 128: rows packed per head, see the header)
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, nullptr, 0, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_QKV_ROPE, 0, -1, -1, 0.f, 0, 0};
-            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = 1.0f; g1.head_dim = d;
+            g1.cs = b.cs; g1.q = b.q; g1.k = b.k; g1.v = b.v; g1.seq = T; g1.nh = nh; g1.nkv = nkv; g1.q_scale = q_fold; g1.head_dim = d;
             P2T_TRY(gemm_nt(g1, s));
         } else {
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
             P2T_TRY(gemm_nt(g1, s));
-            P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, 1.0f, dt, s));
+            P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         }
-        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, s));
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, l2s, s));
         GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g2, s));
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));

@@ -109,7 +109,7 @@ SIGNATURES = {
     "p2t_rmsnorm": (i32, [vp, i64, vp, f32, vp, i64, i64, i64, i32, vp]),
     "p2t_mask_prepare": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "p2t_qkv_post": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
-    "p2t_attention": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp]),
+    "p2t_attention": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, vp]),
     "p2t_esm2_workspace_bytes": (sz, [C.POINTER(EsmConfigC), i32, i32]),
     "p2t_esm2_forward": (i32, [C.POINTER(EsmConfigC), C.POINTER(EsmWeightsC), vp, vp, i32, i32, vp, i64, vp, sz, vp]),
     "p2t_llama_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),

@@ -252,13 +252,14 @@ def qkv_post(qkv: torch.Tensor, inv_freq: torch.Tensor, B: int, T: int, nh: int,
     return q, k, v
 
 
-def attention(q, k, v, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1):
+def attention(q, k, v, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1, log2_scores: bool = False):
+    """softmax(scale q k^T + mask) v; log2_scores: q already carries scale * log2(e) (include/p2t_hip.h, p2t_attention)."""
     B, nh, T, dp = q.shape
     nkv = k.shape[1]
     ld = round_up(nh * d, 64)
     out = torch.empty((B * T, ld), dtype=q.dtype, device=q.device)
     call("p2t_attention", ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(kv_info), ptr(out), ld, B, T, nh, nkv, d, dp,
-         float(scale), int(causal), dt_of(q), use_mfma, stream())
+         float(scale), int(causal), dt_of(q), use_mfma, int(bool(log2_scores)), stream())
     return out
 
 

@@ -426,9 +426,55 @@ def run_sft(ref):
     print(f"wrote {path}: loss {float(out.loss):.6f}, logits {tuple(out.logits.shape)}")
 
 
+def run_sft_backward(ref):
+    """Stage-2 step of the reference (scripts/train_instruct.py:192-213: `loss = model(**batch).loss; loss.backward()`) with the
+    decoder frozen and the adapter trainable, through torch autograd on the reference class (eval mode: no dropout): the LM loss,
+    its gradient with respect to the decoder inputs (after the placeholder scatter) and the adapter's four gradients.  Three
+    decoder shapes: head_dim 16 (the generic path), 64 with GQA and 128 (the fused QKV + rotary epilogues)."""
+    import json
+    cases = {
+        "d16": (specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4, num_key_value_heads=2, vocab_size=512), 64),
+        "d64": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=320, num_attention_heads=4, num_key_value_heads=2, vocab_size=512), 256),
+        "d128": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=288, num_attention_heads=2, num_key_value_heads=1, vocab_size=512,
+                                 rope_type="default", rope_theta=10000.0), 256),
+    }
+    out, metas = {}, {}
+    placeholder_id = 511
+    lens = [10, 6, 3]
+    pid, pmask, ids, mask, labels = sft_batch(3, lens, 18, 9, placeholder_id, 510, 500, 7)
+    t = lambda a: torch.from_numpy(a)
+    for name, (llama, H) in cases.items():
+        esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+        ad = specs.AdapterSpec(64, 96, H, 0.3)
+        model = build_reference_model(ref, esm, llama, ad, 0)
+        model.config.placeholder_id = placeholder_id
+        model.adapter.requires_grad_(True)
+        emb, _ = model(input_ids=t(ids), attention_mask=t(mask), protein_input_ids=t(pid), protein_attention_mask=t(pmask),
+                       return_decoder_inputs=True)
+        emb.retain_grad()
+        res = model.llama_decoder(inputs_embeds=emb, attention_mask=t(mask), labels=t(labels))
+        res.loss.backward()
+        with torch.no_grad():
+            full = model(input_ids=t(ids), attention_mask=t(mask), labels=t(labels), protein_input_ids=t(pid), protein_attention_mask=t(pmask))
+        assert abs(float(full.loss) - float(res.loss)) < 1e-6
+        out[f"{name}.loss"] = np.float32(res.loss.item())
+        out[f"{name}.d_inputs_embeds"] = emb.grad.numpy().copy()
+        for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+            g = dict(model.adapter.named_parameters())[n].grad
+            out[f"{name}.grad.{n}"] = g.numpy().copy()
+        assert model.adapter.ln1.weight.grad is None                       # the unused LayerNorms receive nothing, as in stage 1
+        metas[name] = dict(esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad))
+        print(f"sft_grad {name}: loss {float(res.loss):.6f} |d emb| {float(emb.grad.norm()):.4e} |g fc2.w| {float(model.adapter.fc2.weight.grad.norm()):.4e}")
+    meta = dict(cases=metas, placeholder_id=placeholder_id, lens=lens)
+    path = os.path.join(HERE, "sft_grad_tiny.npz")
+    np.savez_compressed(path, protein_input_ids=pid, protein_attention_mask=pmask, input_ids=ids, attention_mask=mask, labels=labels,
+                        meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
+    print(f"wrote {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft,sft_grad")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -442,6 +488,8 @@ def main():
         run_train_state(ref)
     if "sft" in only:
         run_sft(ref)
+    if "sft_grad" in only:
+        run_sft_backward(ref)
     if "tiny" in only:
         esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
         llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,

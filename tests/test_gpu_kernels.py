@@ -549,6 +549,12 @@ def test_attention_fuzz_mfma_vs_simple(ops):
         scale = float(d) ** -0.5
         a = to_np(ops.attention(q, k, v, key_mask, kv_info, d, scale, causal, use_mfma=1)).reshape(B, T, -1)
         r = to_np(ops.attention(q, k, v, key_mask, kv_info, d, scale, causal, use_mfma=0)).reshape(B, T, -1)
-        assert np.isfinite(a).all(), (it, B, T, nh, nkv, d, causal, lens)
+        # the towers' form for bf16 models: scale * log2(e) folded into q where it is written, the kernel's exponent is q k^T itself
+        q2, _, _ = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, scale * 1.4426950408889634)
+        a2 = to_np(ops.attention(q2, k, v, key_mask, kv_info, d, 1.0, causal, use_mfma=1, log2_scores=True)).reshape(B, T, -1)
+        r2 = to_np(ops.attention(q2, k, v, key_mask, kv_info, d, 1.0, causal, use_mfma=0, log2_scores=True)).reshape(B, T, -1)
+        assert np.isfinite(a).all() and np.isfinite(a2).all(), (it, B, T, nh, nkv, d, causal, lens)
         for b, n in enumerate(lens):
             assert rel(a[b, :n, :nh * d], r[b, :n, :nh * d]) < 1e-2, (it, B, T, nh, nkv, d, causal, lens)
+            assert rel(a2[b, :n, :nh * d], r2[b, :n, :nh * d]) < 1e-2, (it, B, T, nh, nkv, d, causal, lens)      # same operands, both kernels
+            assert rel(a2[b, :n, :nh * d], r[b, :n, :nh * d]) < 2e-2, (it, B, T, nh, nkv, d, causal, lens)       # q rounded after the fold

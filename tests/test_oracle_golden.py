@@ -100,3 +100,24 @@ def test_cfg1_shapes_against_reference(golden):
             assert abs(np.linalg.norm(got.astype(np.float64)) - g[f"gradnorm_seg2_{n}"]) < 1e-3 * g[f"gradnorm_seg2_{n}"]
             got = got[::7, ::5]
         assert rel_err(got, g[f"grad_seg2_{n}"]) < 1e-3, n
+
+
+@pytest.mark.parametrize("case", ["d16", "d64", "d128"])
+def test_sft_backward_oracle_vs_reference_autograd(case):
+    """Stage-2 step (oracle.sft_step: LM loss through the frozen decoder, gradient back to the adapter) against torch autograd
+    through the reference class (tests/golden/sft_grad_tiny.npz, make_golden.py run_sft_backward)."""
+    from oracle import p2t_oracle as O
+    from helpers import model_weights, rel_err
+    from p2t_hip import specs
+    from conftest import load_golden
+    g = load_golden("sft_grad_tiny")
+    m = g["meta"]["cases"][case]
+    esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
+    W = model_weights(esm, llama, ad, 0, lm_head=True)
+    out = O.sft_step(esm, llama, W, g["protein_input_ids"], g["protein_attention_mask"], g["input_ids"], g["attention_mask"], g["labels"],
+                     g["meta"]["placeholder_id"])
+    assert abs(float(out["loss"]) - float(g[f"{case}.loss"])) < 2e-5 * max(1.0, abs(float(g[f"{case}.loss"])))
+    valid = g["attention_mask"] != 0          # padded positions: the reference back-propagates through a uniform softmax row there
+    assert rel_err(out["d_inputs_embeds"][valid], g[f"{case}.d_inputs_embeds"][valid]) < 2e-4
+    for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+        assert rel_err(out["grads"]["adapter." + n], g[f"{case}.grad.{n}"]) < 5e-4, n

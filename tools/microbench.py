@@ -117,8 +117,10 @@ def bench_attn():
         q, k, v = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0)
         ms_post = timeit(lambda: ops.qkv_post(qkv, inv, B, T, nh, nkv, d, 1.0))
         ms = timeit(lambda: ops.attention(q, k, v, km, kv, d, d ** -0.5, causal, use_mfma=1))
+        ms2 = timeit(lambda: ops.attention(q, k, v, km, kv, d, 1.0, causal, use_mfma=1, log2_scores=True))     # timing only: q not re-scaled
         fl = 4.0 * B * nh * T * T * d * (0.5 if causal else 1.0)
-        print(f"attn {name:8s} B={B} T={T} nh={nh}/{nkv} d={d}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s | qkv_post {ms_post:7.3f} ms", flush=True)
+        print(f"attn {name:8s} B={B} T={T} nh={nh}/{nkv} d={d}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s | log2-scores form {ms2:7.3f} ms "
+              f"{fl / ms2 / 1e9:7.1f} TF/s | qkv_post {ms_post:7.3f} ms", flush=True)
 
 
 def bench_norm():
