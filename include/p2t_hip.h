@@ -54,7 +54,7 @@ typedef void* p2t_stream;
 int p2t_version(void);
 const char* p2t_last_error(void);
 /* sizeof() of the ABI structs, for bindings to self-check: 0 esm2_config, 1 esm2_layer, 2 esm2_weights,
- * 3 llama_config, 4 llama_layer, 5 llama_weights, 6 adapter_config, 7 adapter_weights, 8 adapter_saved. */
+ * 3 llama_config, 4 llama_layer, 5 llama_weights, 6 adapter_config, 7 adapter_weights, 8 adapter_saved, 9 llama_layer_t. */
 size_t p2t_struct_size(int which);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
@@ -186,7 +186,20 @@ int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos
  * `scale` is ignored, the result is softmax_2(q k^T + mask) v = the same attention, one multiply-add less per score. */
 int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
                   void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
-                  int dtype, int use_mfma, int log2_scores, p2t_stream stream);
+                  int dtype, int use_mfma, int log2_scores, float* lse, p2t_stream stream);
+/* lse (may be NULL): f32 [B, nh, T], the natural-log sum-exp of every query row's effective logits (scale * q k^T, or
+ * ln 2 * q k^T with log2_scores), +inf for a row without a visible key -- what p2t_attention_backward rebuilds P from.
+ *
+ * Backward of the attention above (exact-fp32 arithmetic on `dtype` operands; stage-2 training, see
+ * p2t_llama_train_backward): with P = exp(logits - lse), D = rowsum(dO o O), dS = P o (dO v^T - D):
+ * dq [B, nh, T, dp] = c dS k, dk [B, nkv, T, dp] = c dS^T q, dv = P^T dO (f32; c = scale, or ln 2 with log2_scores;
+ * GQA: the query heads of a group accumulate into their shared key / value head; padded head dims written as 0).
+ * o / d_o: the attention output and its gradient in the [B*T, ld] layout of p2t_attention's `out`.
+ * D_scratch: f32 [B, nh, T]. */
+int p2t_attention_backward(const void* q, const void* k, const void* v, const void* o, int64_t ld_o, const void* d_o,
+                           int64_t ld_do, const float* lse, const uint8_t* key_mask, const int32_t* kv_info, float* dq,
+                           float* dk, float* dv, float* D_scratch, int B, int T, int nh, int nkv, int d, int dp,
+                           float scale, int causal, int dtype, int log2_scores, p2t_stream stream);
 
 /* ---------------------------------------------------------------- ESM2 encoder */
 typedef struct {
@@ -299,6 +312,56 @@ int p2t_scatter_rows(float* dst, int64_t ld_dst, const int32_t* dst_pos, const v
 int p2t_cross_entropy_shifted(const void* logits, int64_t ld, int dtype, const int64_t* labels, int B, int T, int V,
                               int64_t ignore_index, float* row_loss, int32_t* row_valid, float* loss, int32_t* count,
                               p2t_stream stream);
+
+/* ---------------------------------------------------------------- stage-2 training through the frozen decoder */
+/* The reference's stage-2 step is `loss = model(**batch).loss; loss.backward()` (scripts/train_instruct.py:192-213) on
+ * Esm2LlamaInstructForCausalLM.forward (models/modeling_esm2llama_instruct.py:195-215).  With the decoder frozen the
+ * backward is a chain of dX operations from the LM loss to `inputs_embeds`, whose placeholder rows are the adapter's
+ * outputs (:138) -- the adapter is then differentiated by p2t_adapter_backward.  No LoRA matrices yet.
+ *
+ * d loss / d logits of p2t_cross_entropy_shifted (count: its device-side counter): rows with a counted target get
+ * (softmax - onehot) / count, all others 0; d_logits `dtype` [B*T, ld_d >= V], columns V .. next multiple of 64 zeroed
+ * (the K padding of the LM-head dX GEMM). */
+int p2t_cross_entropy_shifted_backward(const void* logits, int64_t ld, int dtype, const int64_t* labels, int B, int T,
+                                       int V, int64_t ignore_index, const int32_t* count, void* d_logits, int64_t ld_d,
+                                       p2t_stream stream);
+/* LlamaRMSNorm backward (modeling_llama.py:62-67): dx (+)= r (w dy) - x r^3 mean(w dy x), r = rsqrt(mean(x^2) + eps);
+ * x, dx f32, dy `dy_dtype` (F32 / BF16); accumulate != 0 adds into dx (the residual-stream gradient). */
+int p2t_rmsnorm_backward(const float* x, int64_t ld_x, const float* w, float eps, const void* dy, int64_t ld_dy,
+                         int dy_dtype, float* dx, int64_t ld_dx, int64_t rows, int64_t cols, int accumulate,
+                         p2t_stream stream);
+/* dst[dst_pos[r], :H] = src[src_pos[r], :H], r < min(*n_dst, *n_src), f32: the backward of p2t_scatter_rows (the
+ * gradient of `inputs_embeds[placeholder_mask] = encoder_hidden_states[encoder_mask]` with respect to the encoder
+ * states: call it with the two position lists swapped; rows not listed keep their contents -- zero dst first). */
+int p2t_gather_rows_f32(float* dst, int64_t ld_dst, const int32_t* dst_pos, const float* src, int64_t ld_src,
+                        const int32_t* src_pos, const int32_t* n_dst, const int32_t* n_src, int64_t max_rows, int H,
+                        p2t_stream stream);
+/* Transposed decoder weights for the dX GEMMs, `dtype`, one struct per layer (HOST array): each matrix is the forward
+ * weight transposed -- [forward K rows][row stride = forward N rounded up to 64, zero padded] -- built once (the decoder is
+ * frozen).  qkv_wT from the NATURAL row order q_proj | k_proj | v_proj (not the packed order of p2t_llama_layer.qkv_w);
+ * gu_wT from the interleaved gate / up order of p2t_llama_layer.gu_w. */
+typedef struct p2t_llama_layer_t {
+    const void* qkv_wT;     /* [hidden, >= (heads + 2 kv_heads) head_dim] */
+    const void* o_wT;       /* [heads head_dim, >= hidden] */
+    const void* gu_wT;      /* [hidden, >= 2 ffn] */
+    const void* down_wT;    /* [ffn, >= hidden] */
+} p2t_llama_layer_t;
+/* Bytes of the activation "tape" one training forward writes and the backward reads (all n_layers: residual streams
+ * before / inside every layer, rotated heads, attention outputs and log-sum-exps, gate / up pre-activations -- about
+ * 170 KB per token and layer for Llama-3.1-8B: sized for 288 GB of HBM, nothing is recomputed), and of the transient
+ * workspace both calls share. */
+size_t p2t_llama_tape_bytes(const p2t_llama_config* cfg, int B, int T);
+size_t p2t_llama_train_workspace_bytes(const p2t_llama_config* cfg, int B, int T);
+/* p2t_llama_hidden_forward_embeds(k = n_layers) that also fills the tape.  out: f32 [B*T, hidden], post final RMSNorm. */
+int p2t_llama_train_forward(const p2t_llama_config* cfg, const p2t_llama_weights* w, const float* inputs_embeds,
+                            const int64_t* mask, int B, int T, float* out, void* tape, size_t tape_bytes, void* workspace,
+                            size_t workspace_bytes, p2t_stream stream);
+/* d_out: f32 [B*T, hidden] = d loss / d (post-norm hidden states), e.g. d_logits . lm_head.  d_inputs_embeds: f32
+ * [B*T, hidden], overwritten.  The fp32 residual-stream gradient is accumulated in place in d_inputs_embeds; GEMM
+ * operands are `dtype`; dtype BF16 uses the MFMA GEMMs, F32 the exact kernels (parity mode). */
+int p2t_llama_train_backward(const p2t_llama_config* cfg, const p2t_llama_weights* w, const p2t_llama_layer_t* wT,
+                             const int64_t* mask, int B, int T, const float* d_out, const void* tape, size_t tape_bytes,
+                             float* d_inputs_embeds, void* workspace, size_t workspace_bytes, p2t_stream stream);
 
 /* ---------------------------------------------------------------- ModalityAdapter */
 typedef struct {

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256, DP == 64 ? 3 : 2) attn_mfma_kernel(const 
                                                         const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                         const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out,
                                                         int64_t ld_out, int B, int seq, int nh, int nkv, int d,
-                                                        float scale_log2e, int causal, int out_cols) {
+                                                        float scale_log2e, int causal, int out_cols, float* __restrict__ lse) {
     constexpr int RB = DP * 2;                 // tile row bytes
     constexpr int T_BYTES = 64 * RB;           // one tile: 64 keys
     constexpr int STAGE = 2 * T_BYTES;         // K tile + V tile
@@ -319,6 +319,10 @@ __global__ void __launch_bounds__(256, DP == 64 ? 3 : 2) attn_mfma_kernel(const 
     // ---- epilogue: O^T rows = channels (r&3) + 8(r>>2) + 4hh, col = query ----
     if (query < seq) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        // natural-log sum-exp of the effective logits (kernels.h attention()): the exponent reference is m_run in log2 units of the
+        // stored scores (L2S) or in raw-score units (scale_log2e converts); both lanes of a query hold the same value
+        if (lse && hh == 0)
+            lse[(int64_t)(b * nh + h) * seq + query] = l_run > 0.f ? kLn2 * ((L2S ? m_run : m_run * scale_log2e) + __log2f(l_run)) : INFINITY;
         bf16_t* orow = out + ((int64_t)b * seq + query) * ld_out + h * d;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(256, DP == 64 ? 3 : 2) attn_mfma_kernel(const 
 
 int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
                      void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
-                     int log2_scores, hipStream_t s) {
+                     int log2_scores, float* lse, hipStream_t s) {
     P2T_REQUIRE(d % 4 == 0 && (dp == 32 || dp == 64 || dp == 128) && d <= dp && nh % nkv == 0 && (nh * d) % 4 == 0 && ld_out % 4 == 0,
                 "attention(mfma): unsupported shape d=%d dp=%d heads %d/%d", d, dp, nh, nkv);
     const dim3 grid((unsigned)(ceil_div(T, 128) * nh * B));
@@ -350,10 +354,10 @@ int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t*
 #define P2T_ATTN(DPV)                                                                                                        \
     if (log2_scores)                                                                                                         \
         attn_mfma_kernel<DPV, true><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, \
-                                                         (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols);      \
+                                                         (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols, lse); \
     else                                                                                                                     \
         attn_mfma_kernel<DPV, false><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, \
-                                                          (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols)
+                                                          (bf16_t*)out, ld_out, B, T, nh, nkv, d, sl, causal, out_cols, lse)
     if (dp == 32) { P2T_ATTN(32); }
     else if (dp == 64) { P2T_ATTN(64); }
     else { P2T_ATTN(128); }

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ 
                                                           const T* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                           const int32_t* __restrict__ kv_end, T* __restrict__ out,
                                                           int64_t ld_out, int seq, int nh, int nkv, int d, int dp,
-                                                          float scale, int causal, int out_cols) {
+                                                          float scale, int causal, int out_cols, float* __restrict__ lse) {
     __shared__ float s_q[4][128];
     __shared__ float s_p[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ 
         }
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (lse && lane == 0) lse[(int64_t)(b * nh + h) * seq + i] = l > 0.f ? m + logf(l) : INFINITY;      // kernels.h attention(): +inf = no visible key
     T* orow = out + ((int64_t)b * seq + i) * ld_out + h * d;
     if (lane < d) orow[lane] = from_f32<T>(acc0 * inv);
     if (lane + 64 < d) orow[lane + 64] = from_f32<T>(acc1 * inv);
@@ -76,16 +77,16 @@ __global__ void __launch_bounds__(256) attn_simple_kernel(const T* __restrict__ 
 
 int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_end,
                        void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale,
-                       int causal, int dtype, hipStream_t s) {
+                       int causal, int dtype, float* lse, hipStream_t s) {
     P2T_REQUIRE(d % 4 == 0 && d <= 128 && dp <= 128 && nh % nkv == 0, "attention: head_dim %d / heads %d/%d unsupported", d, nh, nkv);
     const dim3 grid((unsigned)ceil_div(T, 4), (unsigned)nh, (unsigned)B);
     const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
     if (dtype == P2T_BF16)
         attn_simple_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_end,
-                                                        (bf16_t*)out, ld_out, T, nh, nkv, d, dp, scale, causal, out_cols);
+                                                        (bf16_t*)out, ld_out, T, nh, nkv, d, dp, scale, causal, out_cols, lse);
     else
         attn_simple_kernel<float><<<grid, 256, 0, s>>>((const float*)q, (const float*)k, (const float*)v, key_mask, kv_end,
-                                                       (float*)out, ld_out, T, nh, nkv, d, dp, scale, causal, out_cols);
+                                                       (float*)out, ld_out, T, nh, nkv, d, dp, scale, causal, out_cols, lse);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -116,18 +116,18 @@ int gemm_nt(const GemmArgs& a, hipStream_t s) {
 
 int attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
               int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype, int use_mfma,
-              int log2_scores, hipStream_t s) {
+              int log2_scores, hipStream_t s, float* lse) {
     P2T_REQUIRE(q && k && v && key_mask && kv_info && out && B > 0 && T > 0 && nh > 0 && nkv > 0, "attention: bad arguments");
     P2T_REQUIRE(ld_out >= (int64_t)nh * d, "attention: ld_out too small");
     if (dtype == P2T_BF16 && use_mfma != 0) {
         const int pi = prof_begin(s, 1, 4.0 * B * nh * (double)T * T * d * (causal ? 0.5 : 1.0));
-        const int rc = launch_attn_mfma(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, log2_scores, s);
+        const int rc = launch_attn_mfma(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, log2_scores, lse, s);
         prof_end(s, pi);
         return rc;
     }
     P2T_REQUIRE(use_mfma != 1, "attention: MFMA kernel needs bf16");
     // exp(ln 2 * (s - m)) = 2^(s - m)
-    return launch_attn_simple(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, log2_scores ? kLn2 : scale, causal, dtype, s);
+    return launch_attn_simple(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, log2_scores ? kLn2 : scale, causal, dtype, lse, s);
 }
 
 }  // namespace p2t
@@ -225,7 +225,7 @@ extern "C" int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq,
 
 extern "C" int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
                              void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
-                             int dtype, int use_mfma, int log2_scores, p2t_stream stream) {
+                             int dtype, int use_mfma, int log2_scores, float* lse, p2t_stream stream) {
     return attention(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, dtype, use_mfma, log2_scores,
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, lse);
 }

@@ -70,15 +70,38 @@ int gemm_nt(const GemmArgs& a, hipStream_t s);
 
 int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
                        int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype,
-                       hipStream_t s);
+                       float* lse, hipStream_t s);
 int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
-                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int log2_scores, hipStream_t s);
+                     int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int log2_scores, float* lse, hipStream_t s);
 // log2_scores: q was stored pre-multiplied by scale * log2(e) (kLog2e below), so q k^T is already the base-2 exponent: `scale` is
 // ignored and p = exp2(s - m).  The towers do this for bf16 models (one multiply + add less per score in the MFMA kernel).
 int attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
               int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype, int use_mfma,
-              int log2_scores, hipStream_t s);
+              int log2_scores, hipStream_t s, float* lse = nullptr);
+// lse (optional, f32 [B, nh, T]): natural-log sum-exp of the effective logits (scale * q.k, or ln 2 * q.k with log2_scores) of
+// every query row, +inf for a row without a visible key -- what the attention backward (llama_train.hip) rebuilds P from.
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+// stage-2 training through the frozen decoder (llama_train.hip): the per-layer activations the backward reads again
+struct LlamaTapeLayer {
+    float* x_in; float* x_mid;          // residual stream before the layer / after its attention branch, f32 [M, H]
+    void* q; void* k; void* v;          // rotated (and, for bf16 models, pre-scaled) heads, `dtype` [B, heads, T, dp]
+    float* lse;                         // f32 [B, nh, T], see attention()
+    void* ao;                           // attention output, `dtype` [M, QO]
+    void* gu;                           // gate / up pre-activations, `dtype` [M, 2F] in the interleaved order of gu_w
+};
+struct LlamaTape {
+    static constexpr int kMaxLayers = 128;
+    int n_layers; bool overflow;
+    float* x_last;                      // input of the final RMSNorm, f32 [M, H]
+    LlamaTapeLayer layer[kMaxLayers];
+};
+size_t llama_tape_plan(const p2t_llama_config* c, int B, int T, void* base, size_t bytes, LlamaTape* tape);
+int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, const float* inputs_embeds, const int64_t* mask,
+                       int B, int T, int k, float* out, void* workspace, size_t workspace_bytes, p2t_stream stream, const LlamaTape* tape);
+int launch_swiglu_from_gu(const void* gu, int64_t ld_gu, void* act, int64_t ld_act, int64_t M, int64_t F, int dtype, hipStream_t s);
+// dst[m, c] = (Tdst)src[m, c] for c < cols, 0 for cols <= c < ld_dst  (a GEMM operand with its K padding)
+int launch_cast_rows(const void* src, int src_dtype, int64_t ld_src, void* dst, int dst_dtype, int64_t ld_dst, int64_t rows, int64_t cols, hipStream_t s);
 
 // adapter tail helpers (adapter.hip)
 int launch_adapter_dz2(const void* g2, const void* z2, const float* inv_norm, const float* dy, void* dz2, int64_t ld, int64_t M,

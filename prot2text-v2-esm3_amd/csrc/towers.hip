@@ -218,9 +218,12 @@ extern "C" size_t p2t_llama_workspace_bytes(const p2t_llama_config* cfg, int B, 
 
 // ids != nullptr: token embedding lookup; else inputs_embeds (f32 [B*T, hidden]) is the layer-0 input (SFT path:
 // placeholder positions already replaced by adapter outputs, reference models/modeling_esm2llama_instruct.py:195-215)
-static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, const float* inputs_embeds,
-                              const int64_t* mask, int B, int T, int k, float* out, void* workspace,
-                              size_t workspace_bytes, p2t_stream stream) {
+// tape != nullptr (p2t_llama_train_forward, llama_train.hip): every layer keeps what the backward reads again -- its input and
+// mid-layer residual streams, the rotated heads, the attention output and log-sum-exps, the gate / up pre-activations (the
+// gate/up GEMM then stores them plainly and SwiGLU runs as its own pass).
+int p2t::llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, const float* inputs_embeds,
+                            const int64_t* mask, int B, int T, int k, float* out, void* workspace,
+                            size_t workspace_bytes, p2t_stream stream, const LlamaTape* tape) {
     P2T_REQUIRE(c && w && (ids || inputs_embeds) && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
     P2T_REQUIRE(k >= 0 && k <= c->n_layers, "p2t_llama_hidden_forward: hidden_states[%d] out of range for %d layers", k, c->n_layers);
     P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 32 == 0 &&
@@ -301,6 +304,13 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
     for (int l = 0; !c->gemm_fp8 && l < k; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_hidden_forward: q_norm_w and k_norm_w go together (layer %d)", l);
+        float* lse = nullptr;
+        if (tape) {                       // this layer's heads / attention output live on the tape instead of the shared workspace
+            const LlamaTapeLayer& S = tape->layer[l];
+            b.q = S.q; b.k = S.k; b.v = S.v; b.ao = S.ao;
+            lse = S.lse;
+            P2T_CHECK_HIP(hipMemcpyAsync(S.x_in, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
+        }
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
         if (L.q_norm_w) {          // Qwen3: projection -> per-head RMSNorm -> rotation (not fusable: the norm spans the head)
             GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)NQKV, 0.f, 0, 0};
@@ -316,16 +326,24 @@ static int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights
             P2T_TRY(gemm_nt(g1, s));
             P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         }
-        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, l2s, s));
+        P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, l2s, s, lse));
         GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g2, s));
+        if (tape) P2T_CHECK_HIP(hipMemcpyAsync(tape->layer[l].x_mid, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
-        GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, b.act, Fp, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_SWIGLU, 0, -1, -1, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g3, s));
+        if (tape) {
+            GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, tape->layer[l].gu, 2 * F, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_STORE, 0, -1, (int)(2 * F), 0.f, 0, 0};
+            P2T_TRY(gemm_nt(g3, s));
+            P2T_TRY(launch_swiglu_from_gu(tape->layer[l].gu, 2 * F, b.act, Fp, M, F, dt, s));
+        } else {
+            GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, b.act, Fp, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_SWIGLU, 0, -1, -1, 0.f, 0, 0};
+            P2T_TRY(gemm_nt(g3, s));
+        }
         GemmArgs g4{b.act, Fp, L.down_w, Fp, nullptr, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         with_fix(g4);
         P2T_TRY(gemm_nt(g4, s));
     }
+    if (tape) P2T_CHECK_HIP(hipMemcpyAsync(tape->x_last, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
     if (k == c->n_layers) return launch_rmsnorm(b.x, H, w->final_norm_w, c->rms_norm_eps, out, H, M, H, P2T_F32, s);
     P2T_CHECK_HIP(hipMemcpyAsync(out, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
     return P2T_OK;
@@ -335,14 +353,14 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
                                         const int64_t* mask, int B, int T, int k, float* out, void* workspace,
                                         size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(ids, "p2t_llama_hidden_forward: null ids");
-    return llama_forward_impl(c, w, ids, nullptr, mask, B, T, k, out, workspace, workspace_bytes, stream);
+    return llama_forward_impl(c, w, ids, nullptr, mask, B, T, k, out, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" int p2t_llama_hidden_forward_embeds(const p2t_llama_config* c, const p2t_llama_weights* w, const float* inputs_embeds,
                                                const int64_t* mask, int B, int T, int k, float* out, void* workspace,
                                                size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(inputs_embeds, "p2t_llama_hidden_forward_embeds: null inputs_embeds");
-    return llama_forward_impl(c, w, nullptr, inputs_embeds, mask, B, T, k, out, workspace, workspace_bytes, stream);
+    return llama_forward_impl(c, w, nullptr, inputs_embeds, mask, B, T, k, out, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" int p2t_llama_embed_tokens(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, int64_t n_tokens,

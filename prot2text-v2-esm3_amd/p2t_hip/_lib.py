@@ -65,6 +65,10 @@ class LlamaWeightsC(C.Structure):
     _fields_ = [("embed", vp), ("layers", C.POINTER(LlamaLayerC)), ("final_norm_w", vp), ("inv_freq", vp)]
 
 
+class LlamaLayerTC(C.Structure):
+    _fields_ = [(n, vp) for n in ("qkv_wT", "o_wT", "gu_wT", "down_wT")]
+
+
 class AdapterConfigC(C.Structure):
     _fields_ = [("input_dim", C.c_int32), ("intermediate_dim", C.c_int32), ("output_dim", C.c_int32),
                 ("dropout_p", f32), ("dropout_seed", u64), ("dtype", C.c_int32)]
@@ -79,7 +83,7 @@ class AdapterSavedC(C.Structure):
 
 
 _STRUCTS = [EsmConfigC, EsmLayerC, EsmWeightsC, LlamaConfigC, LlamaLayerC, LlamaWeightsC, AdapterConfigC,
-            AdapterWeightsC, AdapterSavedC]
+            AdapterWeightsC, AdapterSavedC, LlamaLayerTC]
 
 # name -> (restype, argtypes); every symbol include/p2t_hip.h declares
 SIGNATURES = {
@@ -109,7 +113,16 @@ SIGNATURES = {
     "p2t_rmsnorm": (i32, [vp, i64, vp, f32, vp, i64, i64, i64, i32, vp]),
     "p2t_mask_prepare": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "p2t_qkv_post": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
-    "p2t_attention": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, vp]),
+    "p2t_attention": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, vp, vp]),
+    "p2t_attention_backward": (i32, [vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp]),
+    "p2t_cross_entropy_shifted_backward": (i32, [vp, i64, i32, vp, i32, i32, i32, i64, vp, vp, i64, vp]),
+    "p2t_rmsnorm_backward": (i32, [vp, i64, vp, f32, vp, i64, i32, vp, i64, i64, i64, i32, vp]),
+    "p2t_gather_rows_f32": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, vp]),
+    "p2t_llama_tape_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
+    "p2t_llama_train_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
+    "p2t_llama_train_forward": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, vp, i32, i32, vp, vp, sz, vp, sz, vp]),
+    "p2t_llama_train_backward": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), C.POINTER(LlamaLayerTC), vp, i32, i32, vp, vp, sz,
+                                       vp, vp, sz, vp]),
     "p2t_esm2_workspace_bytes": (sz, [C.POINTER(EsmConfigC), i32, i32]),
     "p2t_esm2_forward": (i32, [C.POINTER(EsmConfigC), C.POINTER(EsmWeightsC), vp, vp, i32, i32, vp, i64, vp, sz, vp]),
     "p2t_llama_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
@@ -150,7 +163,7 @@ for _i, _s in enumerate(_STRUCTS):
     if lib.p2t_struct_size(_i) != C.sizeof(_s):
         raise ImportError(f"ABI mismatch: {_s.__name__} is {C.sizeof(_s)} bytes here, {lib.p2t_struct_size(_i)} in the library")
 
-_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_is_lab_build", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes",
+_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_is_lab_build", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes", "p2t_llama_tape_bytes", "p2t_llama_train_workspace_bytes",
           "p2t_adapter_backward_workspace_bytes"}
 
 

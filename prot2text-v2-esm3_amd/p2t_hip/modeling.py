@@ -414,6 +414,7 @@ class LlamaTextModel(nn.Module):
 
     def invalidate_engine(self):
         self._engine = None
+        self._train_engine = None
 
     def _build_engine(self, n_layers: int):
         s, dt = self.spec, self.dtype
@@ -473,6 +474,59 @@ class LlamaTextModel(nn.Module):
             medium = ~(wavelen < high_wl) * ~(wavelen > low_wl)
             inv = torch.where(medium, smoothed, inv_l)
         return inv.float().contiguous()
+
+    def _build_train_engine(self):
+        """Transposed weights of every layer for the dX GEMMs of the stage-2 backward (include/p2t_hip.h, p2t_llama_layer_t):
+        [forward K][forward N rounded up to 64], built once -- the decoder is frozen on that path."""
+        s, dt = self.spec, self.dtype
+        if self.gemm_fp8:
+            raise ValueError("stage-2 training runs the decoder GEMMs in the model dtype (set_gemm_dtype('model'))")
+        if s.qk_norm:
+            raise NotImplementedError("the per-head q/k RMSNorm of Qwen3 has no backward on this path yet")
+        H, F, L = s.hidden_size, s.intermediate_size, s.num_hidden_layers
+        keep, layers = [], (_lib.LlamaLayerTC * L)()
+        P = dict(self.named_parameters())
+        tr = lambda w: _pad_cols(w.detach().t().contiguous(), round_up(w.shape[0], 64), dt)      # [N, K] -> [K, N padded]
+        for i in range(L):
+            p = f"layers.{i}."
+            qkv = torch.cat([P[p + f"self_attn.{n}_proj.weight"].detach() for n in ("q", "k", "v")], 0)     # NATURAL row order
+            gate, up = P[p + "mlp.gate_proj.weight"].detach(), P[p + "mlp.up_proj.weight"].detach()
+            gu = torch.stack([gate.view(F // 32, 32, H), up.view(F // 32, 32, H)], 1).reshape(2 * F, H)
+            t = dict(qkv_wT=tr(qkv), o_wT=tr(P[p + "self_attn.o_proj.weight"]), gu_wT=tr(gu), down_wT=tr(P[p + "mlp.down_proj.weight"]))
+            keep.append(t)
+            for k, v in t.items():
+                setattr(layers[i], k, v.data_ptr())
+        self._train_engine = dict(layers=layers, keep=keep)
+        return self._train_engine
+
+    def train_forward(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor):
+        """All layers + final RMSNorm from f32 [B, T, hidden] inputs, keeping the activation tape for `train_backward`
+        (p2t_llama_train_forward).  -> (post-norm hidden states f32 [B, T, hidden], tape handle)."""
+        B, T, H = inputs_embeds.shape
+        L = self.spec.num_hidden_layers
+        e = self.ensure_engine(L)
+        dev = self.embed_tokens.weight.device
+        emb = inputs_embeds.to(device=dev, dtype=torch.float32).contiguous()
+        mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        tape = torch.empty((call("p2t_llama_tape_bytes", C.byref(e["cfg"]), B, T),), dtype=torch.uint8, device=dev)
+        ws = self._ws.get(torch.cuda.current_stream().cuda_stream, call("p2t_llama_train_workspace_bytes", C.byref(e["cfg"]), B, T), dev)
+        out = torch.empty((B, T, H), dtype=torch.float32, device=dev)
+        call("p2t_llama_train_forward", C.byref(e["cfg"]), C.byref(e["w"]), ptr(emb), ptr(mask), B, T, ptr(out), ptr(tape), tape.numel(),
+             ptr(ws), ws.numel(), stream())
+        return out, (tape, mask, B, T)
+
+    def train_backward(self, d_out: torch.Tensor, handle) -> torch.Tensor:
+        """d loss / d inputs_embeds (f32 [B, T, hidden]) from d loss / d (post-norm hidden states) and the tape."""
+        tape, mask, B, T = handle
+        L = self.spec.num_hidden_layers
+        e = self.ensure_engine(L)
+        te = getattr(self, "_train_engine", None) or self._build_train_engine()
+        dev = tape.device
+        ws = self._ws.get(torch.cuda.current_stream().cuda_stream, call("p2t_llama_train_workspace_bytes", C.byref(e["cfg"]), B, T), dev)
+        d_in = torch.empty((B, T, self.spec.hidden_size), dtype=torch.float32, device=dev)
+        call("p2t_llama_train_backward", C.byref(e["cfg"]), C.byref(e["w"]), C.cast(te["layers"], C.POINTER(_lib.LlamaLayerTC)), ptr(mask), B, T,
+             ptr(d_out.float().contiguous()), ptr(tape), tape.numel(), ptr(d_in), ptr(ws), ws.numel(), stream())
+        return d_in
 
     def ensure_engine(self, k: int):
         """Packed weights of the first k layers, built now on the current stream if missing."""
@@ -543,6 +597,63 @@ class LlamaTextModel(nn.Module):
         return LlamaTextOutput(LazyHiddenStates(self, input_ids, attention_mask, inputs_embeds))
 
 
+class _ScatterRowsFn(torch.autograd.Function):
+    """`inputs_embeds[placeholder_mask] = encoder_hidden_states[encoder_mask]` (reference :138) with its backward: the gradient of
+    the scattered rows flows back to the encoder (adapter) states, every other encoder row gets zero."""
+
+    @staticmethod
+    def forward(ctx, src2d, holder, dst_pos, n_dst, src_pos, n_src, H):
+        embeds2d = holder[0]                                    # the freshly embedded tokens (no graph of their own), filled in place
+        ops.scatter_rows(embeds2d, dst_pos, n_dst, src2d, src_pos, n_src, H)
+        ctx.save_for_backward(dst_pos, n_dst, src_pos, n_src)
+        ctx.H, ctx.src_shape, ctx.src_dtype = H, tuple(src2d.shape), src2d.dtype
+        return embeds2d
+
+    @staticmethod
+    def backward(ctx, g):
+        dst_pos, n_dst, src_pos, n_src = ctx.saved_tensors
+        g = g.float().contiguous()
+        d_src = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
+        call("p2t_gather_rows_f32", ptr(d_src), d_src.stride(0), ptr(src_pos), ptr(g), g.stride(0), ptr(dst_pos), ptr(n_src), ptr(n_dst),
+             min(dst_pos.numel(), src_pos.numel()), int(ctx.H), stream())
+        return (d_src if ctx.src_dtype == torch.float32 else ops.cast(d_src, ctx.src_dtype)), None, None, None, None, None, None
+
+
+class _DecoderLossFn(torch.autograd.Function):
+    """LM loss of the FROZEN decoder as a function of `inputs_embeds` (reference scripts/train_instruct.py:192-213 with the
+    decoder's parameters frozen): forward = p2t_llama_train_forward -> LM head -> shifted cross-entropy, backward =
+    cross-entropy backward -> LM-head dX GEMM -> p2t_llama_train_backward.  All kernels hand-written; torch only links them."""
+
+    @staticmethod
+    def forward(ctx, inputs_embeds, decoder, attention_mask, labels):
+        s, m = decoder.spec, decoder.model
+        B, T, H = inputs_embeds.shape
+        dt = m.dtype
+        h, handle = m.train_forward(inputs_embeds, attention_mask)
+        a = h.view(B * T, H) if dt == torch.float32 else ops.cast(h.view(B * T, H), dt)
+        logits = ops.gemm_nt(a, decoder._lm_head_padded(), None, n=s.vocab_size, k=H, out_dtype=dt).view(B, T, -1)
+        lab = labels.to(logits.device).to(torch.int64).contiguous()
+        loss, count = ops.cross_entropy_shifted(logits, lab, s.vocab_size)
+        ctx.decoder, ctx.handle, ctx.logits, ctx.labels, ctx.count = decoder, handle, logits, lab, count
+        ctx.mark_non_differentiable(logits)
+        return loss[0], logits
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_logits):
+        dec, logits = ctx.decoder, ctx.logits
+        s = dec.spec
+        B, T, ld = logits.shape
+        H, V = s.hidden_size, s.vocab_size
+        d_logits = torch.empty_like(logits)
+        call("p2t_cross_entropy_shifted_backward", ptr(logits), ld, ops.dt_of(logits), ptr(ctx.labels), B, T, V, -100, ptr(ctx.count), ptr(d_logits), ld,
+             stream())
+        d_h = ops.gemm_nt(d_logits.view(B * T, ld), dec._lm_head_transposed(), None, n=H, k=round_up(V, 64), epilogue=_lib.EPI_STORE_F32)   # [B*T, H] f32
+        d_in = dec.model.train_backward(d_h.view(B, T, H), ctx.handle)
+        call("p2t_scale_by_device_scalar", ptr(d_in), d_in.numel(), ptr(g_loss.float().reshape(1).contiguous()), stream())
+        ctx.handle = ctx.logits = None                          # free the tape
+        return d_in, None, None, None
+
+
 class CausalLMOutput:
     """The fields of HF `CausalLMOutputWithPast` this path fills; indexable like a ModelOutput ((loss,) logits)."""
 
@@ -589,12 +700,22 @@ class LlamaDecoder(nn.Module):
             self._lm_w, self._lm_key = _pad_cols(w.detach(), round_up(self.spec.hidden_size, 64), w.dtype), key
         return self._lm_w
 
+    def _lm_head_transposed(self) -> torch.Tensor:
+        """lm_head.weight^T as the operand of the LM-head dX GEMM: [hidden, vocab rounded up to 64]."""
+        w = self.lm_head.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_lmT_key", None) != key:
+            self._lmT_w, self._lmT_key = _pad_cols(w.detach().t().contiguous(), round_up(w.shape[0], 64), w.dtype), key
+        return self._lmT_w
+
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 cache_position=None, **kwargs):
         """LlamaForCausalLM.forward without a KV cache: all layers -> final RMSNorm -> LM head -> (shifted cross-entropy).
         Restates transformers/models/llama/modeling_llama.py (LlamaForCausalLM.forward) and loss_utils.ForCausalLMLoss.
-        Forward only: the LM loss carries no autograd graph (LoRA training of the decoder is out of scope)."""
+        With `labels`, gradients enabled and `inputs_embeds` requiring grad (stage 2: the adapter's rows sit in it), the loss
+        carries an autograd node whose backward is the hand-written chain of llama_train.hip -- the decoder's own parameters
+        are frozen on this path (no weight gradients; LoRA matrices are not built yet)."""
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         if position_ids is not None or past_key_values is not None or use_cache or cache_position is not None:
@@ -605,6 +726,14 @@ class LlamaDecoder(nn.Module):
         if s.hidden_size % 64:
             raise ValueError("the LM head path needs hidden_size % 64 == 0")
         L = s.num_hidden_layers
+        if labels is not None and inputs_embeds is not None and torch.is_grad_enabled() and inputs_embeds.requires_grad:
+            B, T, _ = inputs_embeds.shape
+            if tuple(labels.shape) != (B, T):
+                raise ValueError(f"labels shape {tuple(labels.shape)} != {(B, T)}")
+            if attention_mask is None:
+                attention_mask = torch.ones((B, T), dtype=torch.int64, device=inputs_embeds.device)
+            loss, logits = _DecoderLossFn.apply(inputs_embeds, self, attention_mask, labels)
+            return CausalLMOutput(loss=loss, logits=logits[..., : s.vocab_size])
         h = m.hidden_state(input_ids, attention_mask, L) if inputs_embeds is None else m.hidden_state_from_embeds(inputs_embeds, attention_mask, L)
         B, T, H = h.shape
         dt = m.dtype
@@ -784,7 +913,10 @@ class Esm2LlamaInstructForCausalLM(PreTrainedModel):
         src = enc.reshape(B * enc.shape[1], H)
         if src.dtype not in (torch.float32, torch.bfloat16) or src.stride(1) != 1:
             src = src.float().contiguous()
-        ops.scatter_rows(embeds.view(B * T, H), dst_pos, n_dst, src, src_pos, n_src, H)
+        if torch.is_grad_enabled() and src.requires_grad:       # stage 2: the gradient of the placeholder rows reaches the adapter
+            embeds = _ScatterRowsFn.apply(src, [embeds.view(B * T, H)], dst_pos, n_dst, src_pos, n_src, H).view(B, T, H)
+        else:
+            ops.scatter_rows(embeds.view(B * T, H), dst_pos, n_dst, src, src_pos, n_src, H)
         nd, ns = int(n_dst.item()), int(n_src.item())          # torch's boolean-mask assignment raises on a count mismatch
         if nd != ns:
             raise RuntimeError(f"shape mismatch: {ns} encoder states cannot be assigned to {nd} placeholder positions")

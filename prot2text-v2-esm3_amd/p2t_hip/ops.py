@@ -252,15 +252,29 @@ def qkv_post(qkv: torch.Tensor, inv_freq: torch.Tensor, B: int, T: int, nh: int,
     return q, k, v
 
 
-def attention(q, k, v, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1, log2_scores: bool = False):
-    """softmax(scale q k^T + mask) v; log2_scores: q already carries scale * log2(e) (include/p2t_hip.h, p2t_attention)."""
+def attention(q, k, v, key_mask, kv_info, d: int, scale: float, causal: bool, use_mfma: int = -1, log2_scores: bool = False,
+              lse: torch.Tensor | None = None):
+    """softmax(scale q k^T + mask) v; log2_scores: q already carries scale * log2(e) (include/p2t_hip.h, p2t_attention).
+    lse (optional f32 [B, nh, T]): filled with the rows' log-sum-exps for p2t_attention_backward."""
     B, nh, T, dp = q.shape
     nkv = k.shape[1]
     ld = round_up(nh * d, 64)
     out = torch.empty((B * T, ld), dtype=q.dtype, device=q.device)
     call("p2t_attention", ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(kv_info), ptr(out), ld, B, T, nh, nkv, d, dp,
-         float(scale), int(causal), dt_of(q), use_mfma, int(bool(log2_scores)), stream())
+         float(scale), int(causal), dt_of(q), use_mfma, int(bool(log2_scores)), ptr(lse), stream())
     return out
+
+
+def attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d: int, scale: float, causal: bool, log2_scores: bool = False):
+    """(dq, dk, dv) f32 in the layouts of q, k, v (include/p2t_hip.h, p2t_attention_backward); o / d_o: [B*T, ld] as `attention` returns."""
+    B, nh, T, dp = q.shape
+    nkv = k.shape[1]
+    f = lambda h: torch.empty((B, h, T, dp), dtype=torch.float32, device=q.device)
+    dq, dk, dv = f(nh), f(nkv), f(nkv)
+    D = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    call("p2t_attention_backward", ptr(q), ptr(k), ptr(v), ptr(o), o.stride(0), ptr(d_o), d_o.stride(0), ptr(lse), ptr(key_mask), ptr(kv_info),
+         ptr(dq), ptr(dk), ptr(dv), ptr(D), B, T, nh, nkv, d, dp, float(scale), int(causal), dt_of(q), int(bool(log2_scores)), stream())
+    return dq, dk, dv
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks on the GPU box (HIP-event timed, random data): GEMM shapes of the
-cfg-3 towers, attention, norms.  Usage: python tools/microbench.py [gemm] [attn] [norm]"""
+cfg-3 towers, attention, norms.  Usage: python tools/microbench.py [gemm] [attn] [norm]
+
+The `gemm` / `cold` / `ksweep` modes force launch forms through p2t_set_gemm_policy: run them against the LAB build
+(P2T_HIP_LIB=tools/build/libp2t_lab.so, `make -C prot2text-v2-esm3_amd/csrc lab`); the product library only knows 0 and 9."""
 import os
 import sys
 
