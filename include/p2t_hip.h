@@ -195,11 +195,12 @@ int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* ke
  * dq [B, nh, T, dp] = c dS k, dk [B, nkv, T, dp] = c dS^T q, dv = P^T dO (f32; c = scale, or ln 2 with log2_scores;
  * GQA: the query heads of a group accumulate into their shared key / value head; padded head dims written as 0).
  * o / d_o: the attention output and its gradient in the [B*T, ld] layout of p2t_attention's `out`.
- * D_scratch: f32 [B, nh, T]. */
+ * D_scratch: f32 [B, nh, T].  use_mfma: -1 auto = the MFMA kernels (csrc/attn_bwd_mfma.hip: bf16, log2_scores, head_dim
+ * 64 / 128; seven MFMA products per tile pair, no float atomics) where they apply, else the exact kernels; 0 = exact; 1 = require. */
 int p2t_attention_backward(const void* q, const void* k, const void* v, const void* o, int64_t ld_o, const void* d_o,
                            int64_t ld_do, const float* lse, const uint8_t* key_mask, const int32_t* kv_info, float* dq,
                            float* dk, float* dv, float* D_scratch, int B, int T, int nh, int nkv, int d, int dp,
-                           float scale, int causal, int dtype, int log2_scores, p2t_stream stream);
+                           float scale, int causal, int dtype, int log2_scores, int use_mfma, p2t_stream stream);
 
 /* ---------------------------------------------------------------- ESM2 encoder */
 typedef struct {

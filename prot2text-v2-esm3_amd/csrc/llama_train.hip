@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
         }
     }
     float* out = dq + ((int64_t)(b * nh + h) * seq + i) * dp;
-    out[lane] = lane < d ? c_s * acc0 : 0.f;
+    if (lane < dp) out[lane] = lane < d ? c_s * acc0 : 0.f;            // (dp = 32: a row is half a wave wide)
     if (dp > 64) out[lane + 64] = lane + 64 < d ? c_s * acc1 : 0.f;
 }
 
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
     float* dkr = dk + ((int64_t)(b * nkv + hk) * seq + j) * dp;
     float* dvr = dv + ((int64_t)(b * nkv + hk) * seq + j) * dp;
     if (!key_mask[(int64_t)b * seq + j]) {                       // a masked key is read by no query
-        dkr[lane] = 0.f; dvr[lane] = 0.f;
+        if (lane < dp) { dkr[lane] = 0.f; dvr[lane] = 0.f; }
         if (dp > 64) { dkr[lane + 64] = 0.f; dvr[lane + 64] = 0.f; }
         return;
     }
@@ -286,20 +286,33 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
             }
         }
     }
-    dkr[lane] = lane < d ? c_s * ak0 : 0.f;
-    dvr[lane] = lane < d ? av0 : 0.f;
+    if (lane < dp) {
+        dkr[lane] = lane < d ? c_s * ak0 : 0.f;
+        dvr[lane] = lane < d ? av0 : 0.f;
+    }
     if (dp > 64) {
         dkr[lane + 64] = lane + 64 < d ? c_s * ak1 : 0.f;
         dvr[lane + 64] = lane + 64 < d ? av1 : 0.f;
     }
 }
 
+int launch_attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, int64_t ld_o, const void* d_o, int64_t ld_do, const float* lse,
+                         const uint8_t* key_mask, const int32_t* kv_info, float* dq, float* dk, float* dv, float* D, int B, int T, int nh, int nkv,
+                         int d, int dp, int causal, hipStream_t s);       // attn_bwd_mfma.hip
+
+// c_s: the factor between q.k and the logits (the softmax scale, or ln 2 in the log2_scores form).  use_mfma: -1 auto (the MFMA
+// kernels for bf16 + log2_scores + head_dim 64 / 128), 0 the exact kernels, 1 require MFMA.
 int launch_attn_bwd(const void* q, const void* k, const void* v, const void* o, int64_t ld_o, const void* d_o, int64_t ld_do, const float* lse,
                     const uint8_t* key_mask, const int32_t* kv_info, float* dq, float* dk, float* dv, float* D, int B, int T, int nh, int nkv,
-                    int d, int dp, float c_s, int causal, int dtype, hipStream_t s) {
+                    int d, int dp, float c_s, int causal, int dtype, hipStream_t s, int log2_scores = 0, int use_mfma = 0) {
     P2T_REQUIRE(q && k && v && o && d_o && lse && key_mask && kv_info && dq && dk && dv && D, "attention backward: null argument");
     P2T_REQUIRE(d % 4 == 0 && d <= 128 && (dp == 32 || dp == 64 || dp == 128) && d <= dp && nh % nkv == 0 && ld_o % 4 == 0 && ld_do % 4 == 0,
                 "attention backward: unsupported shape d=%d dp=%d heads %d/%d", d, dp, nh, nkv);
+    if (dtype == P2T_BF16 && log2_scores && use_mfma != 0) {
+        const int rc = launch_attn_bwd_mfma(q, k, v, o, ld_o, d_o, ld_do, lse, key_mask, kv_info, dq, dk, dv, D, B, T, nh, nkv, d, dp, causal, s);
+        if (rc != P2T_ERR_UNSUPPORTED) return rc;
+    }
+    P2T_REQUIRE(use_mfma != 1, "attention backward: the MFMA kernels need bf16, log2_scores and head_dim 64 / 128");
     const dim3 gq((unsigned)ceil_div(T, 4), (unsigned)nh, (unsigned)B), gk((unsigned)ceil_div(T, 4), (unsigned)nkv, (unsigned)B);
     if (dtype == P2T_BF16) {
         attn_bwd_dq_kernel<bf16_t><<<gq, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, ld_o, (const bf16_t*)d_o,
@@ -555,7 +568,7 @@ extern "C" int p2t_llama_train_backward(const p2t_llama_config* c, const p2t_lla
         P2T_TRY(launch_cast_rows(g, P2T_F32, H, b.g16, dt, Hp, M, H, s));
         P2T_TRY(dx_gemm(b.g16, Hp, LT.o_wT, H, (int64_t)nh * d, b.d_ao, QO, dt, P2T_EPI_STORE));
         P2T_TRY(launch_attn_bwd(S.q, S.k, S.v, S.ao, QO, b.d_ao, QO, S.lse, b.key_mask, b.kv_info, b.dq, b.dk, b.dv, b.D, B, T, nh, nkv, d, dp, c_s, 1,
-                                dt, s));
+                                dt, s, l2s, -1));
         P2T_TRY(launch_rope_bwd_pack(b.dq, b.dk, b.dv, b.cs, b.d_qkv, NQp, B, T, nh, nkv, d, dp, q_fold, dt, s));
         P2T_TRY(dx_gemm(b.d_qkv, NQp, LT.qkv_wT, NQKV, H, b.d_h, H, P2T_F32, P2T_EPI_STORE_F32));
         P2T_TRY(launch_rmsnorm_bwd(S.x_in, H, L.ln1_w, c->rms_norm_eps, b.d_h, H, P2T_F32, g, H, M, H, 1, s));
@@ -566,9 +579,9 @@ extern "C" int p2t_llama_train_backward(const p2t_llama_config* c, const p2t_lla
 extern "C" int p2t_attention_backward(const void* q, const void* k, const void* v, const void* o, int64_t ld_o, const void* d_o, int64_t ld_do,
                                       const float* lse, const uint8_t* key_mask, const int32_t* kv_info, float* dq, float* dk, float* dv,
                                       float* D_scratch, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype,
-                                      int log2_scores, p2t_stream stream) {
+                                      int log2_scores, int use_mfma, p2t_stream stream) {
     return launch_attn_bwd(q, k, v, o, ld_o, d_o, ld_do, lse, key_mask, kv_info, dq, dk, dv, D_scratch, B, T, nh, nkv, d, dp,
-                           log2_scores ? kLn2 : scale, causal, dtype, (hipStream_t)stream);
+                           log2_scores ? kLn2 : scale, causal, dtype, (hipStream_t)stream, log2_scores, use_mfma);
 }
 
 extern "C" int p2t_rmsnorm_backward(const float* x, int64_t ld_x, const float* w, float eps, const void* dy, int64_t ld_dy, int dy_dtype, float* dx,

@@ -114,7 +114,7 @@ SIGNATURES = {
     "p2t_mask_prepare": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "p2t_qkv_post": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "p2t_attention": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, vp, vp]),
-    "p2t_attention_backward": (i32, [vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp]),
+    "p2t_attention_backward": (i32, [vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, vp]),
     "p2t_cross_entropy_shifted_backward": (i32, [vp, i64, i32, vp, i32, i32, i32, i64, vp, vp, i64, vp]),
     "p2t_rmsnorm_backward": (i32, [vp, i64, vp, f32, vp, i64, i32, vp, i64, i64, i64, i32, vp]),
     "p2t_gather_rows_f32": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, vp]),

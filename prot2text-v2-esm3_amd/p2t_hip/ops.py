@@ -265,7 +265,7 @@ def attention(q, k, v, key_mask, kv_info, d: int, scale: float, causal: bool, us
     return out
 
 
-def attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d: int, scale: float, causal: bool, log2_scores: bool = False):
+def attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d: int, scale: float, causal: bool, log2_scores: bool = False, use_mfma: int = -1):
     """(dq, dk, dv) f32 in the layouts of q, k, v (include/p2t_hip.h, p2t_attention_backward); o / d_o: [B*T, ld] as `attention` returns."""
     B, nh, T, dp = q.shape
     nkv = k.shape[1]
@@ -273,7 +273,7 @@ def attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d: int, scale: f
     dq, dk, dv = f(nh), f(nkv), f(nkv)
     D = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
     call("p2t_attention_backward", ptr(q), ptr(k), ptr(v), ptr(o), o.stride(0), ptr(d_o), d_o.stride(0), ptr(lse), ptr(key_mask), ptr(kv_info),
-         ptr(dq), ptr(dk), ptr(dv), ptr(D), B, T, nh, nkv, d, dp, float(scale), int(causal), dt_of(q), int(bool(log2_scores)), stream())
+         ptr(dq), ptr(dk), ptr(dv), ptr(D), B, T, nh, nkv, d, dp, float(scale), int(causal), dt_of(q), int(bool(log2_scores)), int(use_mfma), stream())
     return dq, dk, dv
 
 

@@ -81,7 +81,7 @@ def test_edge_shapes_bf16_mfma_path(golden, shape, case):
         t = P.l2_normalize(P.get_description_embeddings(model, batch["description_input_ids"], batch["description_attention_mask"], k))
     observe(f"edge[{case},B{B}_Tp{Tp}].bf16_vs_bf16oracle.protein", rel(to_np(p), po), 1e-2)
     observe(f"edge[{case},B{B}_Tp{Tp}].bf16_vs_bf16oracle.text", rel(to_np(t), to_), 1e-2)
-    observe(f"edge[{case},B{B}_Tp{Tp}].bf16_vs_bf16oracle.loss", abs(loss - float(O.infonce_batch(po, to_))), 2e-2, "abs")
+    observe(f"edge[{case},B{B}_Tp{Tp}].bf16_vs_bf16oracle.loss", abs(loss - float(O.infonce_batch(po, to_))), 5e-2, "abs")     # logits = 20 x cosine: 6e-3 on the embeddings is 2-3e-2 on this loss
     # gradients: finite, unless the reference's own eps-free std readout hits 0 / 0 -- a two-token protein whose two
     # bf16 adapter rows agree exactly in some column has variance 0 there, and d sqrt(0) is NaN upstream as well
     # (scripts/train_contrast.py:223-235)

@@ -164,6 +164,7 @@ lines = []
 rec = loop.train_epoch(tr, batches, rank=rank, log=lines.append, check_every=2)
 ev = loop.eval_epoch(tr, batches, rank=rank, log=lines.append)
 gl = float(tr.global_loss().cpu()[0])               # last step's loss, averaged over ranks
+params = tr.flat_p.detach().cpu().numpy()[::53].astype(float).tolist()
 # second epoch with a NaN on rank (world - 1) only: the epoch must abort on EVERY rank
 if rank == world - 1:
     tr.w1.fill_(float("nan"))
@@ -173,7 +174,7 @@ try:
 except ValueError:
     aborted = True
 json.dump({"train_loss": rec["train_loss"], "eval_loss": ev["eval_loss"], "batches": rec["batches"], "global_last": gl, "aborted": aborted,
-           "lines": lines, "p": tr.flat_p.detach().cpu().numpy()[::53].astype(float).tolist()}, open(os.environ["P2T_TEST_OUT"] + str(rank), "w"))
+           "lines": lines, "p": params}, open(os.environ["P2T_TEST_OUT"] + str(rank), "w"))
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()

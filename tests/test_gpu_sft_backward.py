@@ -55,12 +55,12 @@ def test_rmsnorm_backward_vs_oracle(dy_dt):
     rows, cols = 37, 320
     x, w = rnd(5, "rb.x", (rows, cols), 2.0, 0.3), rnd(5, "rb.w", (cols,), 0.1, 1.0)
     dy = rnd(5, "rb.dy", (rows, cols), 1.0)
-    dyd = to_dev(dy, dy_dt)
+    dyd, xd, wd = to_dev(dy, dy_dt), to_dev(x), to_dev(w)         # (named: a temporary's memory is recycled once ptr() has returned)
     ref = O.rms_norm_backward(x, w, 1e-5, to_np(dyd).astype(np.float32))
     base = rnd(5, "rb.g", (rows, cols), 1.0)
     for acc in (0, 1):
         out = to_dev(base.copy())
-        _lib.call("p2t_rmsnorm_backward", ptr(to_dev(x)), cols, ptr(to_dev(w)), 1e-5, ptr(dyd), cols, 0 if dy_dt == torch.float32 else 1, ptr(out),
+        _lib.call("p2t_rmsnorm_backward", ptr(xd), cols, ptr(wd), 1e-5, ptr(dyd), cols, 0 if dy_dt == torch.float32 else 1, ptr(out),
                   cols, rows, cols, acc, stream())
         assert rel(to_np(out), ref + (base if acc else 0)) < 3e-6
 
@@ -76,9 +76,10 @@ def test_cross_entropy_backward_vs_numpy(dt):
     labels[0, :5] = -100
     labels[2, -3:] = -100
     lt = to_dev(logits, dt)
-    _, cnt = ops.cross_entropy_shifted(lt, to_dev(labels), V)
+    lab = to_dev(labels)
+    _, cnt = ops.cross_entropy_shifted(lt, lab, V)
     dl = torch.full_like(lt, 7.0)
-    _lib.call("p2t_cross_entropy_shifted_backward", ptr(lt), ld, ops.dt_of(lt), ptr(to_dev(labels)), B, T, V, -100, ptr(cnt), ptr(dl), ld, stream())
+    _lib.call("p2t_cross_entropy_shifted_backward", ptr(lt), ld, ops.dt_of(lt), ptr(lab), B, T, V, -100, ptr(cnt), ptr(dl), ld, stream())
     x = to_np(lt).astype(np.float64)[..., :V]
     p = np.exp(x - x.max(-1, keepdims=True))
     p /= p.sum(-1, keepdims=True)
@@ -100,6 +101,8 @@ CASES = [  # name, B, T, nh, nkv, d, causal, lens (None: full), dtype
     ("d128_bidir", 1, 45, 2, 1, 128, False, [33], torch.float32),
     ("d64_bf16", 2, 130, 4, 2, 64, True, [130, 77], torch.bfloat16),
     ("d128_bf16", 2, 96, 4, 1, 128, True, [96, 50], torch.bfloat16),
+    ("d128_bf16_long_leftpad", 2, 333, 8, 2, 128, True, "left", torch.bfloat16),      # several key / query tiles, GQA 4:1, non-prefix mask
+    ("d64_bf16_bidir", 2, 200, 2, 2, 64, False, [200, 131], torch.bfloat16),
 ]
 
 
@@ -112,7 +115,7 @@ def test_attention_lse_and_backward_vs_numpy(case):
     rng = np.random.default_rng(len(name))
     mask = np.zeros((B, T), dtype=np.int64)
     if lens == "left":                                  # SFT batches: left-padded prompt, right-padded description
-        mask[0, 5:60] = 1
+        mask[0, 5:T - 10] = 1
         mask[1, 0:T] = 1
     else:
         for b, n in enumerate(lens):
@@ -128,7 +131,9 @@ def test_attention_lse_and_backward_vs_numpy(case):
     o = ops.attention(q, k, v, key_mask, kv_info, d, scale, causal, use_mfma=(1 if l2s else 0), log2_scores=l2s, lse=lse)
     d_o = to_dev(bf16r(rnd(4, "ab.do." + name, tuple(o.shape), 1.0)), dt)
     d_o[:, nh * d:] = 0
-    dq, dk, dv = ops.attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d, scale, causal, log2_scores=l2s)
+    forms = {"exact": ops.attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d, scale, causal, log2_scores=l2s, use_mfma=0)}
+    if l2s:                                            # bf16: the MFMA kernels (csrc/attn_bwd_mfma.hip) beside the exact ones
+        forms["mfma"] = ops.attention_backward(q, k, v, o, d_o, lse, key_mask, kv_info, d, scale, causal, log2_scores=True, use_mfma=1)
     # float64 reference on the stored operands
     qn, kn, vn = (to_np(t).astype(np.float64)[..., :d] for t in (q, k, v))
     rep = nh // nkv
@@ -144,7 +149,7 @@ def test_attention_lse_and_backward_vs_numpy(case):
     P = np.divide(E, l, out=np.zeros_like(E), where=l > 0)
     want_lse = np.where(l[..., 0] > 0, m[..., 0] + np.log(np.where(l > 0, l, 1.0))[..., 0], np.inf)
     got_lse = to_np(lse).astype(np.float64)
-    rows = allowed.any(-1)                                # query rows with at least one visible key
+    rows = np.broadcast_to(allowed.any(-1), (B, nh, T))   # query rows with at least one visible key
     assert np.isinf(got_lse[~rows]).all() and (got_lse[~rows] > 0).all()
     assert np.abs(got_lse[rows] - want_lse[rows]).max() < (2e-5 if not l2s else 2e-2)
     On = np.einsum("bhij,bhjd->bhid", P, vr)
@@ -159,10 +164,11 @@ def test_attention_lse_and_backward_vs_numpy(case):
     want_dk = (np.einsum("bhij,bhid->bhjd", dS, qn) * c_s).reshape(B, nkv, rep, T, d).sum(2)
     want_dv = np.einsum("bhij,bhid->bhjd", P, dO).reshape(B, nkv, rep, T, d).sum(2)
     tol = 3e-5 if not l2s else 2e-2                      # bf16: P is rebuilt from an lse of a bf16-probability forward
-    for nm, got, want in (("dq", dq, want_dq), ("dk", dk, want_dk), ("dv", dv, want_dv)):
-        gn = to_np(got).astype(np.float64)
-        assert not gn[..., d:].any(), nm
-        observe(f"attn_bwd[{name}].{nm}", rel(gn[..., :d], want), tol)
+    for form, (dq, dk, dv) in forms.items():
+        for nm, got, want in (("dq", dq, want_dq), ("dk", dk, want_dk), ("dv", dv, want_dv)):
+            gn = to_np(got).astype(np.float64)
+            assert np.isfinite(gn).all() and not gn[..., d:].any(), (form, nm)
+            observe(f"attn_bwd[{name},{form}].{nm}", rel(gn[..., :d], want), tol)
 
 
 def test_gather_rows_undoes_scatter_rows():
@@ -175,8 +181,8 @@ def test_gather_rows_undoes_scatter_rows():
     src_pos, n_src = ops.positions_where(to_dev(mask))
     H = 72
     g = rng.standard_normal((5 * 91, H)).astype(np.float32)
-    out = torch.zeros((5 * 40, H), dtype=torch.float32, device=dev())
-    _lib.call("p2t_gather_rows_f32", ptr(out), H, ptr(src_pos), ptr(to_dev(g)), H, ptr(dst_pos), ptr(n_src), ptr(n_dst), min(dst_pos.numel(), src_pos.numel()),
+    out, gd = torch.zeros((5 * 40, H), dtype=torch.float32, device=dev()), to_dev(g)
+    _lib.call("p2t_gather_rows_f32", ptr(out), H, ptr(src_pos), ptr(gd), H, ptr(dst_pos), ptr(n_src), ptr(n_dst), min(dst_pos.numel(), src_pos.numel()),
               H, stream())
     a, b = np.flatnonzero(ids.reshape(-1) == 3), np.flatnonzero(mask.reshape(-1))
     n = min(len(a), len(b))

@@ -1,6 +1,8 @@
-"""Stage-2 (SFT) FORWARD of Esm2LlamaInstructForCausalLM at cfg3 sizes (forward only -- there is no
-decoder backward yet): ESM2-3B encode -> adapter -> placeholder scatter -> 32-layer Llama-3.1-8B -> LM head -> shifted CE.
-python tools/sft_bench.py [B] > gpurun_out/sft_bench.log   (one line: samples/s, tokens/s, algorithmic TFLOP/s)"""
+"""Stage-2 (SFT) step of Esm2LlamaInstructForCausalLM at cfg3 sizes: ESM2-3B encode -> adapter -> placeholder
+scatter -> 32-layer Llama-3.1-8B -> LM head -> shifted CE, once forward only and once as the training step `loss.backward()`
+(frozen towers, adapter trainable: training forward with the activation tape + the dX chain of csrc/llama_train.hip + adapter
+backward), with a per-kernel-family breakdown of the backward from the torch profiler-free HIP-event brackets below.
+python tools/sft_bench.py [B] > gpurun_out/sft_bench.log"""
 import os
 import sys
 import time
@@ -50,6 +52,28 @@ def main():
     f_ad = 2 * Tp * (He * ad.intermediate_dim + ad.intermediate_dim * Hl)
     f_llama = Ll * T * (2 * (2 * Hl * Hl + 2 * Hl * kv + 3 * Hl * Fl) + 2 * (T + 1) * Hl) + 2 * T * Hl * llama.vocab_size
     f = f_esm + f_ad + f_llama
+    # ---- training step: frozen towers, adapter trainable
+    model.requires_grad_(False)
+    model.adapter.requires_grad_(True)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        o = model(**kw)
+        o.loss.backward()
+        return o
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        o2 = step()
+    torch.cuda.synchronize()
+    dt_train = (time.perf_counter() - t0) / 2
+    gn = float(model.adapter.fc2.weight.grad.float().norm())
+    # the dX chain costs the decoder's linear FLOPs once more (no weight gradients) + attention backward (2.5 x its forward)
+    f_bwd = Ll * T * (2 * (2 * Hl * Hl + 2 * Hl * kv + 3 * Hl * Fl) + 2.5 * 2 * (T + 1) * Hl) + 2 * T * Hl * llama.vocab_size + 2 * f_ad
+    print(f"sft train step cfg3: B={B}: {dt_train * 1e3:.1f} ms/batch = {B / dt_train:.2f} samples/s, {(f + f_bwd) * B / dt_train / 1e12:.0f} TFLOP/s algorithmic "
+          f"(forward {f / 1e12:.2f} + backward {f_bwd / 1e12:.2f} TF/sample); backward alone ~{(dt_train - dt) * 1e3:.1f} ms; loss {float(o2.loss):.4f}, "
+          f"|grad fc2.weight| {gn:.3e}", flush=True)
     print(f"sft forward cfg3: B={B}, {Tp} residues, {T} decoder tokens ({n_desc} supervised): {dt * 1e3:.1f} ms/batch = {B / dt:.2f} samples/s, "
           f"{B * T / dt:.0f} decoder tokens/s, {f * B / dt / 1e12:.0f} TFLOP/s algorithmic ({f / 1e12:.2f} TF/sample: ESM {f_esm / 1e12:.2f}, "
           f"decoder + LM head {f_llama / 1e12:.2f}); loss {float(out.loss):.4f}", flush=True)
