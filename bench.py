@@ -73,17 +73,23 @@ def parse():
 class GpuWeights:
     """dict-like view of the GPU model's parameters as fp32 numpy (fetched per access, never all at once)."""
 
-    def __init__(self, model):
+    def __init__(self, model, cache=False):
         self.p = dict(model.named_parameters())
         self.fetch_s = 0.0            # time spent downloading weights (excluded from the CPU-work figure)
+        self.cache = {} if cache else None      # keep what was fetched (tests that run the oracle several times: ~40 GB of host
+                                                # memory for the cfg3 models)
 
     def __getitem__(self, k):
+        if self.cache is not None and k in self.cache:
+            return self.cache[k]
         t0 = time.perf_counter()
         t = self.p[k]
         if k.endswith("embed_tokens.weight") or k.endswith("word_embeddings.weight"):
             return _Rows(t, self)
         out = t.detach().float().cpu().numpy()
         self.fetch_s += time.perf_counter() - t0
+        if self.cache is not None:
+            self.cache[k] = out
         return out
 
 
