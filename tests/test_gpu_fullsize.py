@@ -102,6 +102,10 @@ def _cfg3_oracle(cfg3, name, prec):
         if "W" not in _ORACLE:
             _ORACLE["W"] = GpuWeights(cfg3["model"], cache=True)        # downloaded once for all precisions and both pairs
         W = _ORACLE["W"]
+        if prec.kind == "fp8":
+            # one padded call: the fp8 oracle quantises every weight matrix per call (the dominant cost), so the pairs share it
+            _ORACLE[name] = O.contrastive_step(cfg3["esm"], cfg3["llama"], W, pid, pmask, tid, tmask, layer=16, num_segments=1, prec=prec)
+            return _ORACLE[name]
         ps, ts = [], []
         for i in range(pid.shape[0]):
             n_p, n_t = int(pmask[i].sum()), int(tmask[i].sum())
