@@ -247,3 +247,56 @@ def test_no_graph_without_trainable_inputs_and_refusals(g):
     bf = _model(g, "d64", torch.bfloat16).set_gemm_dtype("fp8")
     with pytest.raises(Exception, match="model dtype|gemm_fp8"):
         bf(**_inputs(g), labels=to_dev(g["labels"])).loss.backward()
+
+
+def test_fp32_directional_derivative_at_llama8b_layer_shapes():
+    """No golden reaches Llama-3.1-8B's layer shapes (hidden 4096, 32 / 8 heads of 128, FFN 14336, llama3 rotary scaling), so the
+    chain is checked there by a size-independent property: the directional derivative of the LM loss along a random direction of
+    the adapter's fc2.weight, by central differences on the forward, equals <gradient, direction> from the backward (fp32, two
+    decoder layers, left-padded prompts)."""
+    import p2t_hip as P
+    esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=256, num_attention_heads=2)
+    llama = specs.LlamaSpec(num_hidden_layers=2, hidden_size=4096, intermediate_size=14336, num_attention_heads=32, num_key_value_heads=8,
+                            vocab_size=2048, rope_type="llama3", rope_theta=500000.0, rope_factor=8.0)
+    ad = specs.AdapterSpec(128, 192, 4096, 0.0)
+    model = build_model(esm, llama, ad, torch.float32, 5).eval()
+    model.requires_grad_(False)
+    model.adapter.requires_grad_(True)
+    ph = 2047
+    model.config.placeholder_id = ph
+    rng = np.random.default_rng(3)
+    from p2t_hip import synth
+    lens = [20, 9]
+    pid, pmask = synth.protein_batch(9, 2, 22, [n + 2 for n in lens])
+    T_prompt, T_desc = 30, 14
+    ids = np.full((2, T_prompt + T_desc), 2046, dtype=np.int64)
+    mask = np.zeros_like(ids)
+    labels = np.full_like(ids, -100)
+    for b, n in enumerate(lens):
+        prompt = np.concatenate([rng.integers(0, 2000, 3), np.full(n + 2, ph), rng.integers(0, 2000, 2)])
+        ids[b, T_prompt - len(prompt):T_prompt] = prompt
+        mask[b, T_prompt - len(prompt):T_prompt] = 1
+        nd = int(rng.integers(5, T_desc + 1))
+        desc = rng.integers(0, 2000, nd)
+        ids[b, T_prompt:T_prompt + nd] = desc
+        mask[b, T_prompt:T_prompt + nd] = 1
+        labels[b, T_prompt:T_prompt + nd] = desc
+    kw = dict(input_ids=to_dev(ids), attention_mask=to_dev(mask), labels=to_dev(labels), protein_input_ids=to_dev(pid),
+              protein_attention_mask=to_dev(pmask))
+    out = model(**kw)
+    out.loss.backward()
+    w = model.adapter.fc2.weight
+    g = w.grad.detach().clone()
+    direction = torch.from_numpy(rng.standard_normal(tuple(w.shape)).astype(np.float32)).to(w.device)
+    direction *= float(w.detach().norm() / direction.norm())
+    want = float((g * direction).sum())
+    eps = 2e-3
+    with torch.no_grad():
+        base = w.detach().clone()
+        w.copy_(base + eps * direction)
+        lp = float(model(**kw).loss)
+        w.copy_(base - eps * direction)
+        lm = float(model(**kw).loss)
+        w.copy_(base)
+    got = (lp - lm) / (2 * eps)
+    assert abs(want) > 1e-4 and abs(got - want) < 2e-2 * abs(want), (got, want, lp, lm)
