@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define P2T_VERSION 102
+#define P2T_VERSION 103
 
 enum { P2T_OK = 0, P2T_ERR_ARG = -1, P2T_ERR_HIP = -2, P2T_ERR_UNSUPPORTED = -3 };
 enum { P2T_F32 = 0, P2T_BF16 = 1,                         /* storage dtype of weights / activations */
@@ -429,6 +429,64 @@ int p2t_infonce_col_forward(const float* p_all, const float* t_all, int N, int D
  * d_seg[i] (+)= scale / temperature * sum_j (exp(l_ij - col_lse_j) - [j == labels_i]) t_all[j]. */
 int p2t_infonce_col_backward(const float* t_all, const int32_t* labels, const float* logits, const float* col_lse, int S,
                              int N, int D, float temperature, float scale, int accumulate, float* d_seg, p2t_stream stream);
+
+/* ---------------------------------------------------------------- generation: KV cache, prefill, decode steps */
+/* What `llama_decoder.generate(inputs_embeds=..., attention_mask=..., **kwargs)` runs under
+ * Esm2LlamaInstructForCausalLM.generate (models/modeling_esm2llama_instruct.py:217-251): HF GenerationMixin over the cached
+ * LlamaAttention path.  Here: the prompt rows are compacted (valid tokens first: positions 0..len-1 = HF's
+ * cumsum(attention_mask) - 1 on the tokens under the mask), one prefill writes the PROMPT segment of the cache, and every
+ * decode step appends one token per row to the GENERATED segment.  BB = B0 * group rows generate in lock-step (group = beams
+ * per prompt; the beams of a prompt share its prompt segment).  All buffers are the caller's; capacities Tp and G are
+ * multiples of 64; dp = head_dim rounded up to 32 / 64 / 128.  Keys are stored after the rotation, values transposed. */
+typedef struct {
+    void* k_prompt;  void* vt_prompt;   /* `dtype` [n_layers][B0][kv_heads][Tp][dp]  /  [n_layers][B0][kv_heads][dp][Tp] */
+    void* k_gen;     void* vt_gen;      /* `dtype` [n_layers][BB][kv_heads][G][dp]   /  [n_layers][BB][kv_heads][dp][G]  */
+    const int32_t* prompt_len;          /* device i32 [B0]: valid prompt tokens per row (p2t_compact_rows' lens) */
+    int32_t* step;                      /* device i32 [1]: generated tokens already in the cache; a decode step appends at
+                                           index step[0], attends to prompt_len + step[0] + 1 keys and increments it last */
+    int32_t B0, group, Tp, G;
+} p2t_kv_cache;
+
+/* Stable partition of every row by its mask: out[b, r] = x[b, t_r] for the r-th token with mask != 0, rows >= lens[b] zero;
+ * out_mask[b, r] = r < lens[b].  x, out: f32 [B, T, H] (H % 4 == 0, out != x); scratch: i32 [B * T]. */
+int p2t_compact_rows(const float* x, const int64_t* mask, int B, int T, int H, float* out, int64_t* out_mask, int32_t* lens,
+                     int32_t* scratch, p2t_stream stream);
+size_t p2t_llama_prefill_workspace_bytes(const p2t_llama_config* cfg, int B, int T);
+/* All layers over the compacted prompts (mask: prefix masks, as p2t_compact_rows writes them; cache->prompt_len = its lens),
+ * every layer's rotated keys / values into the prompt segment; last_hidden f32 [B, hidden] = the post-final-RMSNorm state of
+ * each row's LAST valid token (the LM head of the first generated token reads it). */
+int p2t_llama_prefill(const p2t_llama_config* cfg, const p2t_llama_weights* w, const float* inputs_embeds, const int64_t* mask,
+                      int B, int T, const p2t_kv_cache* cache, float* last_hidden, void* workspace, size_t workspace_bytes,
+                      p2t_stream stream);
+size_t p2t_llama_decode_workspace_bytes(const p2t_llama_config* cfg, int BB, int Tp, int G);
+/* One token per row: x f32 [BB, hidden] (the embedding of the token chosen last) through all layers at position
+ * prompt_len[row / group] + step[0], its keys / values appended at index step[0], final RMSNorm, LM head
+ * (lm_head `dtype` [vocab, ld_head], ld_head >= hidden rounded up to 64, pad zero) -> logits `dtype` [BB, ld_logits]
+ * (HF keeps the logits in the model dtype and up-casts the last position to f32: generation/utils.py `_sample`); step[0] += 1.
+ * Every length is read on the device: the call can be captured into a HIP graph and replayed. */
+int p2t_llama_decode_step(const p2t_llama_config* cfg, const p2t_llama_weights* w, const void* lm_head, int64_t ld_head,
+                          const p2t_kv_cache* cache, const float* x, void* logits, int64_t ld_logits, void* workspace,
+                          size_t workspace_bytes, p2t_stream stream);
+/* Greedy choice with HF's finished-row rule: next[r] = finished[r] ? pad_id : argmax(logits[r, :V]) (lowest index among equal
+ * maxima, torch.argmax), out_tokens[r, step[0]] = next[r], finished[r] |= next[r] in eos_ids.  eos_ids i64 [n_eos], finished
+ * i32 [BB], next_tokens i64 [BB], out_tokens i64 [BB, ld_tokens >= G]: all on the device. */
+int p2t_greedy_select(const void* logits, int dtype, int64_t ld, int V, int BB, const int64_t* eos_ids, int n_eos,
+                      int64_t pad_id, int32_t* finished, int64_t* next_tokens, int64_t* out_tokens, int64_t ld_tokens,
+                      const int32_t* step, int G, p2t_stream stream);
+/* The decode step's attention on its own (exposed so that it can be checked against the plain arithmetic): ONE query token per
+ * row, q `dtype` [BB, nh, dp], over prompt_len[row / group] keys of the prompt segment and step[0] + 1 keys of the generated
+ * segment (the layouts of ONE layer of p2t_kv_cache), GQA; softmax((scale) q k^T) v with f32 statistics -- log2_scores: q holds
+ * scale * log2(e) already (as the towers store it for bf16 models) and `scale` is ignored.  out `dtype` [BB, ld_out >= nh *
+ * head_dim].  Keys are split over several blocks per (row, kv head) and merged in index order (no float atomics). */
+size_t p2t_attention_decode_workspace_bytes(int B0, int group, int nh, int nkv, int head_dim, int Tp, int G);
+int p2t_attention_decode(const void* q, const void* k_prompt, const void* vt_prompt, const void* k_gen, const void* vt_gen,
+                         const int32_t* prompt_len, const int32_t* step, int B0, int group, int nh, int nkv, int head_dim, int Tp,
+                         int G, float scale, int log2_scores, int dtype, void* out, int64_t ld_out, void* workspace,
+                         size_t workspace_bytes, p2t_stream stream);
+/* Beam re-ordering of the generated segment: row r of (k_dst, vt_dst) = row src_row[r] of the cache's generated segment, the
+ * first step[0] tokens of every layer / head (k_dst, vt_dst: second buffers of the same shape; the caller swaps). */
+int p2t_kv_reorder(const p2t_llama_config* cfg, const p2t_kv_cache* cache, const int64_t* src_row, void* k_dst, void* vt_dst,
+                   p2t_stream stream);
 
 /* ---------------------------------------------------------------- optimizer tail */
 /* One clip_grad_norm_(max_norm) + AdamW step over n_tensors (<= 64) f32 parameter tensors (HOST arrays of

@@ -704,6 +704,128 @@ def sft_step(esm_spec, llama_spec, W, prot_ids, prot_mask, input_ids, attention_
 
 
 # ---------------------------------------------------------------------------------------------
+# generation  (REF models/modeling_esm2llama_instruct.py:217-251 -> HF GenerationMixin.generate with `inputs_embeds`;
+# GEN = transformers/generation/utils.py).  No KV cache here: every step re-runs the decoder over the whole row, which is the
+# same function of (prompt, tokens so far) -- and so an independent check of the cached HIP path.
+# ---------------------------------------------------------------------------------------------
+def _lm_head_weight(spec, W, prefix):
+    Wlm = W[prefix + ("model.embed_tokens.weight" if spec.tie_word_embeddings else "lm_head.weight")]
+    return Wlm if isinstance(Wlm, np.ndarray) else Wlm[np.arange(spec.vocab_size)]
+
+
+def llama_next_token_logits(spec, W, rows, prec: Precision = FP32, prefix="llama_decoder."):
+    """rows: one f32 [n_b, H] array per sequence = the embeddings of its tokens UNDER the attention mask, in order.  HF gives the
+    token under the mask with rank r the position r (`position_ids = cumsum(attention_mask) - 1`, GEN prepare_inputs_for_generation)
+    and hides the masked ones from every query, so dropping them is exact.  -> logits of the last position, f32 [B, V] (rounded to
+    the model dtype first, as HF keeps `outputs.logits` in it before the f32 up-cast of `_sample`)."""
+    Wlm = prec.g(prec.q(_lm_head_weight(spec, W, prefix)))
+    out = []
+    for x in rows:
+        n = x.shape[0]
+        bias = np.where(np.tril(np.ones((n, n), dtype=bool))[None, None], F32(0.0), NEG).astype(F32)
+        cos, sin = rope_cos_sin(llama_inv_freq(spec), np.arange(n))
+        h = np.ascontiguousarray(x[None], dtype=F32)
+        for i in range(spec.num_hidden_layers):
+            h = llama_layer(spec, W, i, h, bias, cos, sin, prec, prefix)
+        last = prec.g(prec.a(rms_norm(h[0, -1:], W[prefix + "model.norm.weight"], spec.rms_norm_eps)))
+        out.append(prec.q((last @ Wlm.T).astype(F32))[0])
+    return np.stack(out).astype(F32)
+
+
+def _prompt_rows(inputs_embeds, mask):
+    return [np.ascontiguousarray(inputs_embeds[b][np.asarray(mask[b]) != 0], dtype=F32) for b in range(len(inputs_embeds))]
+
+
+def generate_greedy(spec, W, inputs_embeds, mask, max_new_tokens, eos_ids=(), pad_id=0, prec: Precision = FP32,
+                    prefix="llama_decoder.", forced=None):
+    """GEN `_sample` with do_sample=False: argmax of the last logits (first index on ties), finished rows emit pad_id, a row finishes
+    when it emits an eos id, the loop stops once every row has.  `forced` (i64 [B, n]): feed these tokens instead of the argmax
+    (teacher forcing, to compare per-step logits of a lower-precision path on the same prefix).
+    -> (tokens i64 [B, n], per-step logits f32 [n, B, V])."""
+    rows = _prompt_rows(inputs_embeds, mask)
+    emb = W[prefix + "model.embed_tokens.weight"]
+    B = len(rows)
+    finished = np.zeros(B, dtype=bool)
+    toks, logs = [], []
+    for step in range(max_new_tokens):
+        lg = llama_next_token_logits(spec, W, rows, prec, prefix)
+        nxt = lg.argmax(-1).astype(np.int64) if forced is None else np.asarray(forced)[:, step].astype(np.int64)
+        if forced is None:
+            nxt[finished] = pad_id
+        toks.append(nxt); logs.append(lg)
+        finished |= np.isin(nxt, list(eos_ids))
+        if forced is None and eos_ids and finished.all():
+            break
+        rows = [np.concatenate([r, emb[np.asarray([t])].astype(F32)], 0) for r, t in zip(rows, nxt)]
+    return np.stack(toks, 1), np.stack(logs, 0)
+
+
+def _log_softmax(x):
+    m = x.max(-1, keepdims=True)
+    return (x - m - np.log(np.exp(x - m, dtype=F32).sum(-1, keepdims=True, dtype=F32))).astype(F32)
+
+
+def _topk(x, k):
+    """torch.topk along the last axis: values descending, lowest index first among equal values."""
+    idx = np.argsort(-x, axis=-1, kind="stable")[..., :k]
+    return np.take_along_axis(x, idx, -1), idx
+
+
+def generate_beam(spec, W, inputs_embeds, mask, max_new_tokens, num_beams, eos_ids=(), pad_id=0, length_penalty=1.0,
+                  early_stopping=False, prec: Precision = FP32, prefix="llama_decoder."):
+    """GEN `_beam_search` (5.x vectorised form) with an empty id prompt (decoder_prompt_len 0, max_length = max_new_tokens): per
+    step the top max(2, 1 + n_eos) * num_beams continuations of every prompt by accumulated log-probability; those that hit a
+    stopping criterion (eos, max length) compete -- length-normalised by (cur_len + 1) ** length_penalty -- for the num_beams
+    finished slots if they were among the top num_beams, the best num_beams others go on; the loop ends when no running beam can
+    still beat the worst finished one (the early_stopping=False heuristic), or nothing is left to continue.
+    -> (sequences i64 [B, n] of the best hypothesis per prompt, its score f32 [B])."""
+    rows0 = _prompt_rows(inputs_embeds, mask)
+    emb = W[prefix + "model.embed_tokens.weight"]
+    B, nb, V, L = len(rows0), num_beams, spec.vocab_size, max_new_tokens
+    keep = max(2, 1 + len(eos_ids)) * nb
+    top_mask = np.arange(keep) < nb
+    running = np.full((B, nb, L), pad_id, dtype=np.int64)
+    sequences = running.copy()
+    run_sc = np.zeros((B, nb), dtype=F32); run_sc[:, 1:] = -1e9
+    beam_sc = np.full((B, nb), -1e9, dtype=F32)
+    done = np.zeros((B, nb), dtype=bool)
+    lens_done = np.zeros((B, nb), dtype=np.int64)
+    open_ = np.ones((B, 1), dtype=bool)
+    cur = 0
+    gather = lambda t, i: np.take_along_axis(t, i.reshape(i.shape + (1,) * (t.ndim - 2)), 1)
+    while True:
+        rows = [np.concatenate([rows0[b], emb[running[b, j, :cur]].astype(F32)], 0) for b in range(B) for j in range(nb)]
+        lp = _log_softmax(llama_next_token_logits(spec, W, rows, prec, prefix)).reshape(B, nb, V)
+        acc = (lp + run_sc[:, :, None]).reshape(B, nb * V)
+        top_lp, top_i = _topk(acc, keep)
+        src = top_i // V
+        top_seq = gather(running, src).copy()
+        top_seq[:, :, cur] = top_i % V
+        hits = np.full((B, keep), cur + 1 >= L) | np.isin(top_seq[:, :, cur], list(eos_ids))
+        live = (top_lp + hits.astype(F32) * F32(-1e9)).astype(F32)
+        _, nxt = _topk(live, nb)
+        running, run_sc = gather(top_seq, nxt), gather(live, nxt)
+        just = hits & top_mask[None]
+        fin = (top_lp / F32((cur + 1) ** length_penalty)).astype(F32)
+        full = done.all(-1, keepdims=True) & (early_stopping is True)
+        fin = fin + full.astype(F32) * F32(-1e9) + (~open_).astype(F32) * F32(-1e9) + (~just).astype(F32) * F32(-1e9)
+        m_seq, m_sc = np.concatenate([sequences, top_seq], 1), np.concatenate([beam_sc, fin], 1)
+        m_done = np.concatenate([done, just], 1)
+        m_len = np.concatenate([lens_done, np.full((B, keep), cur + 1)], 1)
+        _, sel = _topk(m_sc, nb)
+        sequences, beam_sc, done, lens_done = gather(m_seq, sel), gather(m_sc, sel), gather(m_done, sel), gather(m_len, sel)
+        cur += 1
+        best_len = L if (early_stopping == "never" and length_penalty > 0.0) else cur
+        best_running = run_sc[:, :1] / F32(best_len ** length_penalty)
+        worst_done = np.where(done, beam_sc.min(1, keepdims=True), F32(-1e9))
+        open_ = open_ & (best_running > worst_done).any(-1, keepdims=True)
+        if not (open_.any() and not (done.all() and early_stopping is True) and not hits.all()):
+            break
+    n = int(lens_done[:, 0].max())
+    return sequences[:, 0, :n], beam_sc[:, 0]
+
+
+# ---------------------------------------------------------------------------------------------
 # optimizer tail  (REF scripts/train_contrast.py:453-465,621-626: clip_grad_norm_ then AdamW)
 # ---------------------------------------------------------------------------------------------
 def clip_and_adamw(params, grads, m, v, step, lr=2e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,

@@ -98,7 +98,10 @@ struct LlamaTape {
 };
 size_t llama_tape_plan(const p2t_llama_config* c, int B, int T, void* base, size_t bytes, LlamaTape* tape);
 int llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, const float* inputs_embeds, const int64_t* mask,
-                       int B, int T, int k, float* out, void* workspace, size_t workspace_bytes, p2t_stream stream, const LlamaTape* tape);
+                       int B, int T, int k, float* out, void* workspace, size_t workspace_bytes, p2t_stream stream, const LlamaTape* tape,
+                       const p2t_kv_cache* kv = nullptr);
+// generation prefill (llama_decode.hip): layer l's rotated keys / values ([B, kv_heads, T, dp]) -> the prompt segment of the cache
+int llama_kv_store(const p2t_llama_config* c, const p2t_kv_cache* kc, int layer, const void* k, const void* v, int B, int T, hipStream_t s);
 int launch_swiglu_from_gu(const void* gu, int64_t ld_gu, void* act, int64_t ld_act, int64_t M, int64_t F, int dtype, hipStream_t s);
 // dst[m, c] = (Tdst)src[m, c] for c < cols, 0 for cols <= c < ld_dst  (a GEMM operand with its K padding)
 int launch_cast_rows(const void* src, int src_dtype, int64_t ld_src, void* dst, int dst_dtype, int64_t ld_dst, int64_t rows, int64_t cols, hipStream_t s);

@@ -199,6 +199,7 @@ extern "C" size_t p2t_struct_size(int which) {
         case 7: return sizeof(p2t_adapter_weights);
         case 8: return sizeof(p2t_adapter_saved);
         case 9: return sizeof(p2t_llama_layer_t);
+        case 10: return sizeof(p2t_kv_cache);
     }
     return 0;
 }

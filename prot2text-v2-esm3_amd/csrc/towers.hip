@@ -223,7 +223,7 @@ extern "C" size_t p2t_llama_workspace_bytes(const p2t_llama_config* cfg, int B, 
 // gate/up GEMM then stores them plainly and SwiGLU runs as its own pass).
 int p2t::llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, const float* inputs_embeds,
                             const int64_t* mask, int B, int T, int k, float* out, void* workspace,
-                            size_t workspace_bytes, p2t_stream stream, const LlamaTape* tape) {
+                            size_t workspace_bytes, p2t_stream stream, const LlamaTape* tape, const p2t_kv_cache* kv) {
     P2T_REQUIRE(c && w && (ids || inputs_embeds) && mask && out && workspace && B > 0 && T > 0, "p2t_llama_hidden_forward: null/empty argument");
     P2T_REQUIRE(k >= 0 && k <= c->n_layers, "p2t_llama_hidden_forward: hidden_states[%d] out of range for %d layers", k, c->n_layers);
     P2T_REQUIRE(c->heads % c->kv_heads == 0 && c->head_dim % 4 == 0 && c->head_dim <= 128 && c->hidden % 16 == 0 && c->ffn % 32 == 0 &&
@@ -291,6 +291,7 @@ int p2t::llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* 
             P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         }
         P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, l2s, s));
+        if (kv) P2T_TRY(llama_kv_store(c, kv, l, b.k, b.v, B, T, s));
         P2T_TRY(launch_quant_rows(b.ao, dt, QO, M, (int64_t)nh * d, b.aoq, QOq, b.aos, s));
         GemmArgs g2 = fp8(b.aoq, QOq, b.aos, L.o_w, L.o_ws, b.x, H, H, QOq, P2T_F32, P2T_EPI_RESID);
         P2T_TRY(gemm_nt(g2, s));
@@ -327,6 +328,7 @@ int p2t::llama_forward_impl(const p2t_llama_config* c, const p2t_llama_weights* 
             P2T_TRY(launch_qkv_post(b.qkv, NQKV, b.cs, b.q, b.k, b.v, B, T, nh, nkv, d, dp, q_fold, dt, s));
         }
         P2T_TRY(attention(b.q, b.k, b.v, b.key_mask, b.kv_info, b.ao, QO, B, T, nh, nkv, d, dp, scale, 1, dt, -1, l2s, s, lse));
+        if (kv) P2T_TRY(llama_kv_store(c, kv, l, b.k, b.v, B, T, s));      // generation prefill: this layer's keys / values -> prompt segment
         GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g2, s));
         if (tape) P2T_CHECK_HIP(hipMemcpyAsync(tape->layer[l].x_mid, b.x, sizeof(float) * (size_t)M * H, hipMemcpyDeviceToDevice, s));
@@ -353,14 +355,14 @@ extern "C" int p2t_llama_hidden_forward(const p2t_llama_config* c, const p2t_lla
                                         const int64_t* mask, int B, int T, int k, float* out, void* workspace,
                                         size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(ids, "p2t_llama_hidden_forward: null ids");
-    return llama_forward_impl(c, w, ids, nullptr, mask, B, T, k, out, workspace, workspace_bytes, stream, nullptr);
+    return llama_forward_impl(c, w, ids, nullptr, mask, B, T, k, out, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" int p2t_llama_hidden_forward_embeds(const p2t_llama_config* c, const p2t_llama_weights* w, const float* inputs_embeds,
                                                const int64_t* mask, int B, int T, int k, float* out, void* workspace,
                                                size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(inputs_embeds, "p2t_llama_hidden_forward_embeds: null inputs_embeds");
-    return llama_forward_impl(c, w, nullptr, inputs_embeds, mask, B, T, k, out, workspace, workspace_bytes, stream, nullptr);
+    return llama_forward_impl(c, w, nullptr, inputs_embeds, mask, B, T, k, out, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" int p2t_llama_embed_tokens(const p2t_llama_config* c, const p2t_llama_weights* w, const int64_t* ids, int64_t n_tokens,

@@ -747,8 +747,14 @@ class LlamaDecoder(nn.Module):
             loss = ops.cross_entropy_shifted(logits, labels.to(logits.device), s.vocab_size)[0][0]
         return CausalLMOutput(loss=loss, logits=logits[..., : s.vocab_size])
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError("generation is out of scope for the contrastive path")
+    def generate(self, inputs=None, attention_mask=None, inputs_embeds=None, **kwargs):
+        """`LlamaForCausalLM.generate` over the KV-cache decode path (p2t_hip/generation.py): prompts as `inputs_embeds` (what
+        Esm2LlamaInstructForCausalLM.generate passes, reference :246-250) or as ids (`inputs` / `input_ids`); greedy, sampling
+        (temperature / top_k / top_p) and beam search (num_beams, length_penalty).  The result holds the NEW tokens only (HF does
+        the same for `inputs_embeds`; for id prompts HF prepends the prompt, this path does not)."""
+        from . import generation
+        ids = kwargs.pop("input_ids", inputs)
+        return generation.generate(self, inputs_embeds=inputs_embeds, attention_mask=attention_mask, input_ids=ids, **kwargs)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -950,8 +956,17 @@ class Esm2LlamaInstructForCausalLM(PreTrainedModel):
                                           use_cache=use_cache, output_attentions=output_attentions, return_dict=return_dict,
                                           cache_position=cache_position)                                              # :204-215
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError("generation is out of scope for the contrastive path")
+    def generate(self, inputs: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, protein_input_ids: Optional[torch.Tensor] = None,
+                 protein_attention_mask: Optional[torch.Tensor] = None, protein_inputs_embeds: Optional[torch.Tensor] = None, **kwargs):
+        """Reference :217-251: `inputs` is the [prompt] only; the prompt embeddings (placeholders replaced by the adapter rows) come
+        from `forward(return_decoder_inputs=True)` and go to `llama_decoder.generate(inputs_embeds=, attention_mask=, **kwargs)`.
+        The output does not repeat the prompt (it went in as embeddings)."""
+        with torch.no_grad():
+            prompt_embeds, prompt_mask = self(input_ids=inputs, attention_mask=attention_mask, protein_input_ids=protein_input_ids,
+                                              protein_attention_mask=protein_attention_mask, protein_inputs_embeds=protein_inputs_embeds,
+                                              use_cache=False, output_attentions=False, output_hidden_states=False, return_dict=False,
+                                              return_decoder_inputs=True)
+        return self.llama_decoder.generate(inputs_embeds=prompt_embeds, attention_mask=prompt_mask, **kwargs)
 
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
         """Accepted for loop compatibility (reference :253-261; `transformers.Trainer(gradient_checkpointing=True)` passes

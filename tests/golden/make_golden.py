@@ -471,10 +471,77 @@ def run_sft_backward(ref):
                         meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
     print(f"wrote {path}")
 
+def run_generate(ref):
+    """`Esm2LlamaInstructForCausalLM.generate` of the reference (models/modeling_esm2llama_instruct.py:217-251) on tiny random-init
+    towers, driven as scripts/generate_instruct.py:72-87 drives it: left-padded prompts holding protein placeholders, greedy decoding
+    (with and without an eos id that some rows hit early), and beam search with two length penalties.  Per-step logits of the greedy
+    run are kept so that a port can be checked step by step; the smallest top-1 / top-2 logit gap of every greedy run is asserted to
+    be far above fp32 noise, so the token ids are a stable target."""
+    import json
+    cases = {
+        "d16": (specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4, num_key_value_heads=2, vocab_size=512), 64),
+        "d64": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=320, num_attention_heads=4, num_key_value_heads=2, vocab_size=512), 256),
+        "d128": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=288, num_attention_heads=2, num_key_value_heads=1, vocab_size=512,
+                                 rope_type="default", rope_theta=10000.0), 256),
+        "qwen3": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=192, num_attention_heads=4, num_key_value_heads=2, vocab_size=512,
+                                  head_dim=48, qk_norm=True, rope_type="default", rope_theta=10000.0, tie_word_embeddings=False), 128),
+    }
+    out, metas = {}, {}
+    placeholder_id, pad_id, n_new = 511, 510, 14
+    lens = [10, 6, 3]
+    T_prompt = 18
+    pid, pmask, ids, mask, _ = sft_batch(3, lens, T_prompt, 9, placeholder_id, pad_id, 500, 11)
+    ids, mask = ids[:, :T_prompt].copy(), mask[:, :T_prompt].copy()          # the [prompt] only, left padded
+    t = lambda a: torch.from_numpy(a)
+    for name, (llama, H) in cases.items():
+        esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+        ad = specs.AdapterSpec(64, 96, H, 0.3)
+        kw = dict(inputs=t(ids), attention_mask=t(mask), protein_input_ids=t(pid), protein_attention_mask=t(pmask), pad_token_id=pad_id,
+                  return_dict_in_generate=True)
+        for wseed in range(8):                                               # first weight seed whose greedy choices are all clear-cut
+            model = build_reference_model(ref, esm, llama, ad, wseed)
+            model.config.placeholder_id = placeholder_id
+            with torch.no_grad():
+                g0 = model.generate(**kw, max_new_tokens=n_new, eos_token_id=None, do_sample=False, num_beams=1, output_logits=True)
+            seq0 = g0.sequences.numpy()
+            lg = torch.stack(g0.logits, 0).numpy()                           # [n_new, B, V]
+            top2 = np.sort(lg, axis=-1)[..., -2:]
+            gap = float((top2[..., 1] - top2[..., 0]).min())
+            if gap > 5e-3:
+                break
+        assert seq0.shape == (3, n_new) and gap > 5e-3, (seq0.shape, gap)
+        eos = int(seq0[1, 4])                                                # row 1 stops after five tokens (others whenever they emit it)
+        with torch.no_grad():
+            g1 = model.generate(**kw, max_new_tokens=n_new, eos_token_id=eos, do_sample=False, num_beams=1)
+            # the argument set of scripts/generate_instruct.py:72-87 (sampling switches passed but off)
+            g1b = model.generate(**kw, max_new_tokens=n_new, eos_token_id=eos, num_beams=1, length_penalty=1.0, temperature=1.0, do_sample=False,
+                                 top_p=1.0, top_k=50)
+            assert torch.equal(g1.sequences, g1b.sequences)
+            beams = {}
+            for lp in (1.0, 0.5):
+                gb = model.generate(**kw, max_new_tokens=n_new, eos_token_id=eos, do_sample=False, num_beams=3, length_penalty=lp, output_scores=True)
+                beams[lp] = (gb.sequences.numpy(), gb.sequences_scores.numpy())
+        seq1 = g1.sequences.numpy()
+        assert (seq1[1, :5] == seq0[1, :5]).all() and (seq1[1, 5:] == pad_id).all()
+        out[f"{name}.greedy"] = seq0
+        out[f"{name}.greedy_logits"] = lg.astype(np.float32)
+        out[f"{name}.greedy_eos"] = seq1
+        for lp, (sq, sc) in beams.items():
+            out[f"{name}.beam3_lp{lp}"] = sq
+            out[f"{name}.beam3_lp{lp}_scores"] = sc.astype(np.float32)
+        metas[name] = dict(esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad), eos=eos, min_top2_gap=gap, weight_seed=wseed)
+        print(f"generate {name}: greedy {seq0[0, :6]}..., min top-2 gap {gap:.3e}, eos {eos} -> widths {seq1.shape[1]}, beams "
+              f"{[(k, v[0].shape, np.round(v[1], 4).tolist()) for k, v in beams.items()]}")
+    meta = dict(cases=metas, placeholder_id=placeholder_id, pad_id=pad_id, lens=lens, max_new_tokens=n_new)
+    path = os.path.join(HERE, "generate_tiny.npz")
+    np.savez_compressed(path, protein_input_ids=pid, protein_attention_mask=pmask, input_ids=ids, attention_mask=mask,
+                        meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
+    print(f"wrote {path}")
+
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft,sft_grad")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft,sft_grad,generate")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -490,6 +557,8 @@ def main():
         run_sft(ref)
     if "sft_grad" in only:
         run_sft_backward(ref)
+    if "generate" in only:
+        run_generate(ref)
     if "tiny" in only:
         esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
         llama = specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4,

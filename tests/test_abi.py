@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/p2t_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in p2t_hip/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.version() == 102
+    assert _lib.version() == 103
 
 
 def test_struct_sizes_match():

@@ -1,0 +1,246 @@
+"""`generate` of Esm2LlamaInstructForCausalLM (reference models/modeling_esm2llama_instruct.py:217-251; call site
+scripts/generate_instruct.py:72-87) on the KV-cache decode path (csrc/llama_decode.hip, p2t_hip/generation.py).
+
+* the kernels one by one against numpy: prompt compaction, single-query attention over the two cache segments (both dtypes, head_dim
+  16 / 48 / 64 / 128, GQA groups 1 / 2 / 4 / 5, split-KV on and off, beams sharing a prompt segment), beam re-ordering of the
+  generated segment, the greedy choice with ties / finished rows;
+* the whole call against `model.generate` of the REFERENCE class (tests/golden/generate_tiny.npz, make_golden.py run_generate):
+  left-padded prompts holding protein placeholders; fp32: greedy ids exact and per-step logits to 2e-4 (eager steps and the replayed
+  HIP graph), the finished-row rule under an eos id, beam search (3 beams, two length penalties) ids exact and scores to 1e-4; four
+  decoder shapes (generic head_dim 16, 64 with GQA, 128 with the packed rows, Qwen3 with q/k norms and head_dim 48);
+* bf16: per-step logits against the bf16-rounding oracle fed the SAME tokens (teacher forcing), and against the model's own
+  cache-less forward over prompt + generated tokens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import p2t_oracle as O
+from gpu_util import build_model, dev, observe, rel, rnd, to_dev, to_np
+from helpers import model_weights
+from p2t_hip import specs
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = ["d16", "d64", "d128", "qwen3"]
+
+
+@pytest.fixture(scope="module")
+def g():
+    z = np.load(os.path.join(HERE, "golden", "generate_tiny.npz"))
+    d = {k: z[k] for k in z.files}
+    d["meta"] = json.loads(bytes(d.pop("meta_json")).decode())
+    return d
+
+
+def _model(g, case, dtype):
+    m = g["meta"]["cases"][case]
+    model = build_model(specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"]), dtype, m["weight_seed"])
+    model.config.placeholder_id = g["meta"]["placeholder_id"]
+    model.eval()
+    return model
+
+
+def _inputs(g):
+    return dict(inputs=to_dev(g["input_ids"]), attention_mask=to_dev(g["attention_mask"]), protein_input_ids=to_dev(g["protein_input_ids"]),
+                protein_attention_mask=to_dev(g["protein_attention_mask"]))
+
+
+# ---------------------------------------------------------------------------------------------
+def test_compact_rows_vs_numpy():
+    from p2t_hip import _lib
+    from p2t_hip.ops import ptr, stream
+    B, T, H = 5, 300, 24
+    x = rnd(3, "cr.x", (B, T, H), 1.0)
+    rs = np.random.RandomState(0)
+    mask = (rs.rand(B, T) < 0.6).astype(np.int64)
+    mask[1] = 0; mask[1, 200:] = 1            # left padding
+    mask[2] = 1                               # nothing to move
+    mask[3] = 0; mask[3, 7] = 1               # a single token
+    mask[4] = 0                               # an empty row (the caller refuses it; the kernel must not misbehave)
+    xd, md = to_dev(x), to_dev(mask)
+    out, om = torch.full((B, T, H), 7.0, device=dev()), torch.empty_like(md)
+    lens, scr = torch.empty((B,), dtype=torch.int32, device=dev()), torch.empty((B * T,), dtype=torch.int32, device=dev())
+    _lib.call("p2t_compact_rows", ptr(xd), ptr(md), B, T, H, ptr(out), ptr(om), ptr(lens), ptr(scr), stream())
+    o, l, m2 = to_np(out), to_np(lens), to_np(om)
+    for b in range(B):
+        n = int(mask[b].sum())
+        assert l[b] == n
+        assert np.array_equal(o[b, :n], x[b][mask[b] != 0]) and not o[b, n:].any()
+        assert np.array_equal(m2[b], (np.arange(T) < n).astype(np.int64))
+
+
+def _attn_ref(q, kp, vp, kg, vg, lens, step, group, scale):
+    """q [BB, nh, d]; prompt keys/values [B0, nkv, Tp, d], generated [BB, nkv, G, d] -> [BB, nh, d]"""
+    BB, nh, d = q.shape
+    nkv = kp.shape[1]
+    G = nh // nkv
+    out = np.zeros((BB, nh, d), dtype=np.float32)
+    for bb in range(BB):
+        b0 = bb // group
+        for h in range(nh):
+            kv = h // G
+            k = np.concatenate([kp[b0, kv, :lens[b0]], kg[bb, kv, :step + 1]], 0)
+            v = np.concatenate([vp[b0, kv, :lens[b0]], vg[bb, kv, :step + 1]], 0)
+            s = (k @ q[bb, h]) * scale
+            p = np.exp(s - s.max())
+            out[bb, h] = (p / p.sum()) @ v
+    return out
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(16, 4, 2, 1, 100, 3), (64, 4, 2, 2, 700, 70), (128, 8, 2, 1, 1500, 130), (48, 5, 1, 3, 64, 0),
+                                   (128, 2, 2, 1, 5, 63), (64, 16, 1, 1, 200, 9)])
+def test_decode_attention_vs_numpy(dt, shape):
+    """p2t_attention_decode (the decode step's attention on its own) against softmax(q k^T) v over the concatenated valid keys; NaN
+    behind every valid prefix proves nothing outside it is read into a result."""
+    from p2t_hip import _lib, ops
+    from p2t_hip.ops import ptr, stream
+    d, nh, nkv, group, n0max, step = shape
+    dp = ops.head_dim_padded(d)
+    B0 = 3
+    BB = B0 * group
+    Tp, G = ops.round_up(n0max, 64), ops.round_up(step + 1, 64)
+    lens = np.array([n0max, max(1, n0max // 3), 1], dtype=np.int32)
+    rs = np.random.RandomState(d + nh)
+    f = lambda *s: (rs.randn(*s) * 0.7).astype(np.float32)
+    q, kp, vp, kg, vg = f(BB, nh, d), f(B0, nkv, Tp, d), f(B0, nkv, Tp, d), f(BB, nkv, G, d), f(BB, nkv, G, d)
+    # garbage (NaN) behind the valid prefixes: the kernel must neither read it into a result nor multiply it by zero
+    for b in range(B0):
+        kp[b, :, lens[b]:] = np.nan; vp[b, :, lens[b]:] = np.nan
+    kg[:, :, step + 1:] = np.nan; vg[:, :, step + 1:] = np.nan
+    pad = lambda a: np.concatenate([a, np.zeros(a.shape[:-1] + (dp - d,), np.float32)], -1)
+    rd = lambda a: to_np(to_dev(a, dt)).astype(np.float32)
+    qd = to_dev(pad(q), dt)
+    kpd, kgd = to_dev(pad(kp), dt), to_dev(pad(kg), dt)
+    vtp, vtg = to_dev(np.ascontiguousarray(pad(vp).transpose(0, 1, 3, 2)), dt), to_dev(np.ascontiguousarray(pad(vg).transpose(0, 1, 3, 2)), dt)
+    lens_d, step_d = to_dev(lens), torch.tensor([step], dtype=torch.int32, device=dev())
+    scale = d ** -0.5
+    l2s = dt == torch.bfloat16
+    QO = ops.round_up(nh * d, 64)
+    out = torch.zeros((BB, QO), dtype=dt, device=dev())
+    ws = torch.empty((_lib.call("p2t_attention_decode_workspace_bytes", B0, group, nh, nkv, d, Tp, G),), dtype=torch.uint8, device=dev())
+    _lib.call("p2t_attention_decode", ptr(qd), ptr(kpd), ptr(vtp), ptr(kgd), ptr(vtg), ptr(lens_d), ptr(step_d), B0, group, nh, nkv, d, Tp, G,
+              float(scale), int(l2s), ops.dt_of(dt), ptr(out), QO, ptr(ws), ws.numel(), stream())
+    qq = rd(pad(q))[..., :d]
+    ref = _attn_ref(qq, np.nan_to_num(rd(pad(kp)))[..., :d], np.nan_to_num(rd(pad(vp)))[..., :d], np.nan_to_num(rd(pad(kg)))[..., :d],
+                    np.nan_to_num(rd(pad(vg)))[..., :d], lens, step, group, (np.log(2.0) if l2s else scale))
+    got = to_np(out).astype(np.float32)[:, : nh * d].reshape(BB, nh, d)
+    assert np.isfinite(got).all()
+    if dt == torch.float32:
+        assert rel(got, ref) < 3e-6
+    else:
+        observe(f"decode_attn[d{d},nh{nh},nkv{nkv},g{group},n{n0max},s{step}].bf16", rel(got, ref), 1.2e-2)
+
+
+def test_greedy_select_ties_and_finished_rows():
+    from p2t_hip import _lib, ops
+    from p2t_hip.ops import ptr, stream
+    V, ld, BB, G = 1000, 1024, 4, 64
+    for dt in (torch.float32, torch.bfloat16):
+        lg = np.full((BB, ld), -5.0, dtype=np.float32)
+        lg[0, [900, 17, 400]] = 3.0                   # a three-way tie: torch.argmax returns the lowest index
+        lg[1, 999] = 1.0; lg[1, 1001] = 9.0           # columns >= V are padding
+        lg[2, 5] = 2.0                                # an eos id
+        lg[3, 8] = 4.0                                # finished before: emits pad
+        lgd = to_dev(lg, dt)
+        eos = torch.tensor([5, 77], dtype=torch.int64, device=dev())
+        fin = torch.tensor([0, 0, 0, 1], dtype=torch.int32, device=dev())
+        nxt, out = torch.zeros((BB,), dtype=torch.int64, device=dev()), torch.full((BB, G), -1, dtype=torch.int64, device=dev())
+        step = torch.tensor([3], dtype=torch.int32, device=dev())
+        _lib.call("p2t_greedy_select", ptr(lgd), ops.dt_of(dt), ld, V, BB, ptr(eos), 2, 555, ptr(fin), ptr(nxt), ptr(out), G, ptr(step), G, stream())
+        assert to_np(nxt).tolist() == [17, 999, 5, 555]
+        assert to_np(out)[:, 3].tolist() == [17, 999, 5, 555] and (to_np(out)[:, :3] == -1).all()
+        assert to_np(fin).tolist() == [0, 0, 1, 1]
+        assert to_np(nxt).tolist() == torch.where(fin.cpu().bool() & torch.tensor([False, False, False, True]), torch.tensor(555),
+                                                   torch.from_numpy(lg[:, :V]).argmax(1)).tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fp32_greedy_vs_reference_generate(g, case, use_graph):
+    model = _model(g, case, torch.float32)
+    meta = g["meta"]
+    n, pad = meta["max_new_tokens"], meta["pad_id"]
+    out = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, num_beams=1,
+                         return_dict_in_generate=True, output_logits=True, use_graph=use_graph)
+    assert np.array_equal(to_np(out.sequences), g[f"{case}.greedy"])
+    lg = torch.stack(out.logits, 0)
+    assert np.abs(to_np(lg) - g[f"{case}.greedy_logits"]).max() < 2e-4
+    # the argument set of scripts/generate_instruct.py:72-87 (sampling switches passed but off), with rows that stop early
+    eos = meta["cases"][case]["eos"]
+    seq = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=eos, pad_token_id=pad, return_dict_in_generate=False, num_beams=1,
+                         length_penalty=1.0, temperature=1.0, do_sample=False, top_p=1.0, top_k=50, use_graph=use_graph, sync_every=4)
+    assert np.array_equal(to_np(seq), g[f"{case}.greedy_eos"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fp32_beam_search_vs_reference_generate(g, case):
+    model = _model(g, case, torch.float32)
+    meta = g["meta"]
+    for lp in ("1.0", "0.5"):
+        out = model.generate(**_inputs(g), max_new_tokens=meta["max_new_tokens"], eos_token_id=meta["cases"][case]["eos"], pad_token_id=meta["pad_id"],
+                             do_sample=False, num_beams=3, length_penalty=float(lp), return_dict_in_generate=True, output_scores=True)
+        assert np.array_equal(to_np(out.sequences), g[f"{case}.beam3_lp{lp}"]), lp
+        assert np.abs(to_np(out.sequences_scores) - g[f"{case}.beam3_lp{lp}_scores"]).max() < 1e-4, lp
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16_steps_vs_bf16_oracle_and_own_forward(g, case):
+    """bf16: the greedy ids may leave the fp32 path's at a near-tie, so the comparison is per step on the SAME tokens: the oracle
+    with bf16 rounding is teacher-forced with the ids the GPU chose; and the model's own cache-less forward over prompt + those ids
+    must give the same last-position logits (KV-cache path == full forward)."""
+    model = _model(g, case, torch.bfloat16)
+    meta = g["meta"]
+    m = meta["cases"][case]
+    n, pad = 8, meta["pad_id"]
+    out = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True,
+                         output_logits=True)
+    toks, lg = to_np(out.sequences), to_np(torch.stack(out.logits, 0))
+    esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
+    W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
+    emb, mask = model(input_ids=to_dev(g["input_ids"]), attention_mask=to_dev(g["attention_mask"]), protein_input_ids=to_dev(g["protein_input_ids"]),
+                      protein_attention_mask=to_dev(g["protein_attention_mask"]), return_decoder_inputs=True)
+    _, ref = O.generate_greedy(llama, W, to_np(emb), to_np(mask), n, (), pad, prec=O.BF16, forced=toks)
+    observe(f"generate[{case}].bf16_vs_bf16oracle.logits", rel(lg, ref), 4e-2)
+    # own cache-less forward: prompt (still left padded: positions differ from the compacted ones only on rows WITHOUT padding ...
+    # so compare on the compacted prompt) + the generated ids
+    dec = model.llama_decoder
+    for b in range(toks.shape[0]):
+        valid = to_np(mask)[b] != 0
+        row = torch.cat([emb[b][torch.from_numpy(valid).to(emb.device)], dec.model.embed(to_dev(toks[b:b + 1, :-1]))[0]], 0)[None]
+        full = to_np(dec(inputs_embeds=row).logits.float())[0]
+        n0 = int(valid.sum())
+        observe(f"generate[{case}].bf16_cache_vs_full_forward.row{b}", rel(lg[:, b], full[n0 - 1:n0 - 1 + n]), 3e-2)
+
+
+def test_sampling_is_seeded_and_respects_the_filters(g):
+    model = _model(g, "d64", torch.float32)
+    meta = g["meta"]
+    kw = dict(max_new_tokens=6, eos_token_id=None, pad_token_id=meta["pad_id"], do_sample=True, temperature=0.7, top_k=5, top_p=0.9)
+    gen = torch.Generator(device=dev())
+    a = model.generate(**_inputs(g), **kw, generator=gen.manual_seed(3))
+    b = model.generate(**_inputs(g), **kw, generator=gen.manual_seed(3))
+    c = model.generate(**_inputs(g), **kw, generator=gen.manual_seed(4))
+    assert torch.equal(a, b) and a.shape == (3, 6) and not torch.equal(a, c)
+    # top_k = 1 is greedy whatever the seed
+    d = model.generate(**_inputs(g), max_new_tokens=6, eos_token_id=None, pad_token_id=meta["pad_id"], do_sample=True, top_k=1, generator=gen.manual_seed(9))
+    assert np.array_equal(to_np(d), g["d64.greedy"][:, :6])
+
+
+def test_generate_refusals(g):
+    model = _model(g, "d16", torch.float32)
+    with pytest.raises(ValueError):
+        model.llama_decoder.generate(inputs_embeds=torch.zeros((1, 4, 64), device=dev()), attention_mask=torch.zeros((1, 4), dtype=torch.int64, device=dev()),
+                                     max_new_tokens=2)                       # a row without a single token under the mask
+    with pytest.raises(ValueError):
+        model.llama_decoder.generate(inputs_embeds=torch.zeros((1, 4, 64), device=dev()))       # no length budget
+    with pytest.raises(NotImplementedError):
+        model.generate(**_inputs(g), max_new_tokens=2, num_beams=2, do_sample=True)
+    # ids instead of embeddings: the decoder alone (HF would return prompt + new tokens; here the new tokens, documented)
+    ids = to_dev(np.array([[3, 4, 5, 6]], dtype=np.int64))
+    out = model.llama_decoder.generate(ids, max_new_tokens=3, pad_token_id=0)
+    assert out.shape == (1, 3)

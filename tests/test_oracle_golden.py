@@ -121,3 +121,34 @@ def test_sft_backward_oracle_vs_reference_autograd(case):
     assert rel_err(out["d_inputs_embeds"][valid], g[f"{case}.d_inputs_embeds"][valid]) < 2e-4
     for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
         assert rel_err(out["grads"]["adapter." + n], g[f"{case}.grad.{n}"]) < 5e-4, n
+
+
+@pytest.mark.parametrize("case", ["d16", "d64", "d128", "qwen3"])
+def test_generate_oracle_vs_reference_generate(case):
+    """oracle.generate_greedy / generate_beam (cache-less restatement of HF `_sample` / `_beam_search` under the reference's
+    `generate`, models/modeling_esm2llama_instruct.py:217-251) against `model.generate` of the reference class itself
+    (tests/golden/generate_tiny.npz, make_golden.py run_generate): left-padded prompts with protein placeholders; greedy ids exact
+    (the fixture's smallest top-2 logit gap is >= 5e-3) with per-step logits to 2e-4, the finished-row padding rule under an eos id,
+    and beam search (3 beams, two length penalties): ids exact, scores to 1e-4."""
+    from oracle import p2t_oracle as O
+    from helpers import model_weights
+    from p2t_hip import specs
+    from conftest import load_golden
+    g = load_golden("generate_tiny")
+    meta = g["meta"]
+    m = meta["cases"][case]
+    esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
+    W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
+    enc = O.esm2_forward(esm, W, g["protein_input_ids"], g["protein_attention_mask"], O.FP32, prefix="esm_encoder.")
+    emb = O.sft_decoder_inputs(llama, W, g["input_ids"], O.adapter_forward(W, enc, O.FP32, prefix="adapter."), g["protein_attention_mask"],
+                               meta["placeholder_id"])
+    n, pad, eos = meta["max_new_tokens"], meta["pad_id"], m["eos"]
+    toks, logits = O.generate_greedy(llama, W, emb, g["attention_mask"], n, (), pad)
+    assert np.array_equal(toks, g[f"{case}.greedy"])
+    assert np.abs(logits - g[f"{case}.greedy_logits"]).max() < 2e-4
+    toks_e, _ = O.generate_greedy(llama, W, emb, g["attention_mask"], n, (eos,), pad)
+    assert np.array_equal(toks_e, g[f"{case}.greedy_eos"])
+    for lp in ("1.0", "0.5"):
+        seq, sc = O.generate_beam(llama, W, emb, g["attention_mask"], n, 3, (eos,), pad, float(lp))
+        assert np.array_equal(seq, g[f"{case}.beam3_lp{lp}"]), lp
+        assert np.abs(sc - g[f"{case}.beam3_lp{lp}_scores"]).max() < 1e-4, lp

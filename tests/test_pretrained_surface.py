@@ -34,8 +34,10 @@ def test_is_a_pretrained_model_with_the_reference_surface():
     m.gradient_checkpointing_disable()
     assert not m.is_gradient_checkpointing
     m.gradient_checkpointing_enable()                                                             # as the reference's scripts call it
-    with pytest.raises(NotImplementedError):
-        m.generate()
+    import inspect
+    sig = inspect.signature(m.generate)                                                           # reference :217-225
+    assert list(sig.parameters)[:5] == ["inputs", "attention_mask", "protein_input_ids", "protein_attention_mask", "protein_inputs_embeds"]
+    assert callable(m.llama_decoder.generate)
 
 
 def test_save_and_load_with_hf_keywords(tmp_path):
