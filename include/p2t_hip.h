@@ -459,30 +459,47 @@ int p2t_llama_prefill(const p2t_llama_config* cfg, const p2t_llama_weights* w, c
                       int B, int T, const p2t_kv_cache* cache, float* last_hidden, void* workspace, size_t workspace_bytes,
                       p2t_stream stream);
 size_t p2t_llama_decode_workspace_bytes(const p2t_llama_config* cfg, int BB, int Tp, int G);
+/* Optional second copies of the four projection weights of a layer in the STREAM order of the decode GEMM (p2t_preshuffle_w;
+ * bf16 models; built once per generate-capable model: 288 GB of HBM hold both layouts of an 8-B decoder many times over).
+ * w_stream: HOST array of n_layers entries or NULL (the step then streams p2t_llama_layer's own matrices, 64-byte pieces of 16
+ * rows per load instead of whole lines: 8-30 % slower per GEMM). */
+typedef struct { const void* qkv_w; const void* o_w; const void* gu_w; const void* down_w; } p2t_llama_layer_stream;
 /* One token per row: x f32 [BB, hidden] (the embedding of the token chosen last) through all layers at position
  * prompt_len[row / group] + step[0], its keys / values appended at index step[0], final RMSNorm, LM head
  * (lm_head `dtype` [vocab, ld_head], ld_head >= hidden rounded up to 64, pad zero) -> logits `dtype` [BB, ld_logits]
  * (HF keeps the logits in the model dtype and up-casts the last position to f32: generation/utils.py `_sample`); step[0] += 1.
+ * lm_head_preshuffled: lm_head is the p2t_preshuffle_w copy (ld_head ignored).
  * Every length is read on the device: the call can be captured into a HIP graph and replayed. */
-int p2t_llama_decode_step(const p2t_llama_config* cfg, const p2t_llama_weights* w, const void* lm_head, int64_t ld_head,
-                          const p2t_kv_cache* cache, const float* x, void* logits, int64_t ld_logits, void* workspace,
-                          size_t workspace_bytes, p2t_stream stream);
+int p2t_llama_decode_step(const p2t_llama_config* cfg, const p2t_llama_weights* w, const p2t_llama_layer_stream* w_stream,
+                          const void* lm_head, int64_t ld_head, int lm_head_preshuffled, const p2t_kv_cache* cache,
+                          const float* x, void* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes,
+                          p2t_stream stream);
 /* Greedy choice with HF's finished-row rule: next[r] = finished[r] ? pad_id : argmax(logits[r, :V]) (lowest index among equal
  * maxima, torch.argmax), out_tokens[r, step[0]] = next[r], finished[r] |= next[r] in eos_ids.  eos_ids i64 [n_eos], finished
  * i32 [BB], next_tokens i64 [BB], out_tokens i64 [BB, ld_tokens >= G]: all on the device. */
 int p2t_greedy_select(const void* logits, int dtype, int64_t ld, int V, int BB, const int64_t* eos_ids, int n_eos,
                       int64_t pad_id, int32_t* finished, int64_t* next_tokens, int64_t* out_tokens, int64_t ld_tokens,
                       const int32_t* step, int G, p2t_stream stream);
+/* The decode step's projections on their own: out[M, N] = A[M, K] . W[N, K]^T for M <= 64 rows of bf16 -- a weight stream (every
+ * byte of W read once, 8 waves split K per 16 output features, partial sums added in wave order; HBM-bound, not MFMA-bound).
+ * K % 32 == 0, lda / ldw multiples of 8, no bias.  epilogue: P2T_EPI_STORE (out_dtype P2T_BF16 or P2T_F32), P2T_EPI_STORE_F32,
+ * P2T_EPI_RESID (out f32, += ), P2T_EPI_SWIGLU (W = the gate/up interleave of p2t_llama_layer.gu_w with N = 2 F rows, out bf16
+ * [M, F]).  w_preshuffled: W is the p2t_preshuffle_w copy (ldw ignored).  Anything else: P2T_ERR_UNSUPPORTED. */
+int p2t_gemm_nt_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, int w_preshuffled, void* out, int64_t ldc, int64_t M,
+                       int64_t N, int64_t K, int out_dtype, int epilogue, p2t_stream stream);
+/* W bf16 [N, ldw] -> the stream order the decode GEMM reads with whole-line loads: out[((t * K/32 + s) * 64 + lane) * 8 + e] =
+ * W[16 t + lane % 16][32 s + 8 (lane / 16) + e], rows N .. next multiple of 16 as zeros; out: bf16 [round_up(N, 16) * K].
+ * K % 32 == 0.  Pass the result to p2t_gemm_nt_skinny with w_preshuffled = 1 (same N, K). */
+int p2t_preshuffle_w(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, p2t_stream stream);
 /* The decode step's attention on its own (exposed so that it can be checked against the plain arithmetic): ONE query token per
  * row, q `dtype` [BB, nh, dp], over prompt_len[row / group] keys of the prompt segment and step[0] + 1 keys of the generated
  * segment (the layouts of ONE layer of p2t_kv_cache), GQA; softmax((scale) q k^T) v with f32 statistics -- log2_scores: q holds
  * scale * log2(e) already (as the towers store it for bf16 models) and `scale` is ignored.  out `dtype` [BB, ld_out >= nh *
- * head_dim].  Keys are split over several blocks per (row, kv head) and merged in index order (no float atomics). */
-size_t p2t_attention_decode_workspace_bytes(int B0, int group, int nh, int nkv, int head_dim, int Tp, int G);
+ * head_dim].  One block per (row, kv head) streams all its keys; its waves are merged in LDS in wave order (no atomics).  use_mfma: -1 / 1
+ * = the matrix-pipe kernel for bf16 (what the decode step runs), 0 = the lane-per-key kernel (every dtype; f32 always). */
 int p2t_attention_decode(const void* q, const void* k_prompt, const void* vt_prompt, const void* k_gen, const void* vt_gen,
                          const int32_t* prompt_len, const int32_t* step, int B0, int group, int nh, int nkv, int head_dim, int Tp,
-                         int G, float scale, int log2_scores, int dtype, void* out, int64_t ld_out, void* workspace,
-                         size_t workspace_bytes, p2t_stream stream);
+                         int G, float scale, int log2_scores, int dtype, int use_mfma, void* out, int64_t ld_out, p2t_stream stream);
 /* Beam re-ordering of the generated segment: row r of (k_dst, vt_dst) = row src_row[r] of the cache's generated segment, the
  * first step[0] tokens of every layer / head (k_dst, vt_dst: second buffers of the same shape; the caller swaps). */
 int p2t_kv_reorder(const p2t_llama_config* cfg, const p2t_kv_cache* cache, const int64_t* src_row, void* k_dst, void* vt_dst,

@@ -229,3 +229,17 @@ extern "C" int p2t_attention(const void* q, const void* k, const void* v, const 
     return attention(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, dtype, use_mfma, log2_scores,
                      (hipStream_t)stream, lse);
 }
+
+// The decode step's GEMM on its own (gemm_skinny.hip): see include/p2t_hip.h
+extern "C" int p2t_preshuffle_w(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, p2t_stream stream) {
+    return p2t::launch_preshuffle(W, ldw, N, K, out, (hipStream_t)stream);
+}
+
+extern "C" int p2t_gemm_nt_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, int w_preshuffled, void* out, int64_t ldc, int64_t M, int64_t N,
+                                  int64_t K, int out_dtype, int epilogue, p2t_stream stream) {
+    P2T_REQUIRE(A && W && out, "p2t_gemm_nt_skinny: null argument");
+    const int r = p2t::launch_gemm_skinny(A, lda, W, ldw, out, ldc, M, N, K, P2T_BF16, out_dtype, epilogue, (hipStream_t)stream, w_preshuffled != 0);
+    if (r == P2T_ERR_UNSUPPORTED) p2t::set_error("p2t_gemm_nt_skinny: unsupported shape / epilogue (M %lld, N %lld, K %lld, epilogue %d)", (long long)M,
+                                                 (long long)N, (long long)K, epilogue);
+    return r;
+}

@@ -67,6 +67,12 @@ struct GemmArgs {
     const uint8_t* out_row_scale = nullptr;        // P2T_EPI_GELU_FP8: E8M0 byte of every output row
 };
 int gemm_nt(const GemmArgs& a, hipStream_t s);
+// weight-streaming GEMM for M <= 64 rows (gemm_skinny.hip): bf16, epilogues STORE / STORE_F32 / RESID / SWIGLU, no bias;
+// P2T_ERR_UNSUPPORTED for anything else
+// pre: W is the pre-shuffled stream copy written by launch_preshuffle (ldw unused)
+int launch_gemm_skinny(const void* x, int64_t lda, const void* W, int64_t ldw, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype,
+                       int out_dtype, int epilogue, hipStream_t s, int pre = 0);
+int launch_preshuffle(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s);
 
 int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
                        int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype,

@@ -144,11 +144,9 @@ __global__ void __launch_bounds__(256) rope_append_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // attention of ONE query token per row over the two cache segments
 // ---------------------------------------------------------------------------------------------
-// grid (BB * nkv, NS, head chunks); block = 4 waves.  The keys of a (row, kv head) are cut into 64-key tiles (prompt segment, then
-// generated segment); tile t goes to wave (t mod 4 NS) of the NS blocks that share the pair (split-KV: B * nkv alone is far fewer
-// than 256 CUs' worth of blocks).  A wave keeps a running (max, sum, output) per query head of the GQA group -- they all read the
-// same keys -- in base-2 form; the four waves are merged in LDS, the NS blocks through `part` by the block that arrives last
-// (`counter`, which it resets), always in index order: no float atomics, the result does not depend on arrival order.
+// grid (BB * nkv, head chunks): ONE block owns all keys of a (row, kv head) -- cut into 64-key tiles (prompt segment, then generated
+// segment), tile t goes to wave t mod NW.  A wave keeps a running (max, sum, output) per query head of the GQA group -- they all read
+// the same keys -- in base-2 form; the waves are merged in LDS in wave order (decode_merge): no atomics, nothing through memory.
 //   scores: lane = key, 16-byte pieces of its K row against q (f32 in LDS, broadcast reads);
 //   values: lane = feature (rows of the transposed segment), 16-byte pieces = 8 (bf16) / 4 (f32) consecutive keys against P in LDS.
 template <typename T> struct Piece;
@@ -158,23 +156,47 @@ template <typename T, int N> __device__ __forceinline__ void load_piece(const T*
     if constexpr (N == 8) load8(p, v); else load4(p, v);
 }
 
+// Merge of a block's per-wave results (red[w][head][0..DP-1] = un-normalised output, [DP] = running max, [DP + 1] = sum; base-2 form),
+// in wave order, and the store of the normalised rows.  One block owns ALL keys of its (row, kv head): a split over several blocks
+// with a last-arriver merge through global memory was measured at 42 us per launch against 24 for this form at 8 x 1121 keys -- three
+// more dependent round trips to memory and a release fence per block cost more than the idle CUs.
+template <typename T, int DP, int GH, int NW>
+__device__ __forceinline__ void decode_merge(float (&red)[NW][GH][DP + 2], int bb, int h0, int nhead, int d, T* __restrict__ out, int64_t ld_out) {
+    for (int i = threadIdx.x; i < GH * DP; i += NW * 64) {
+        const int g = i / DP, c = i - g * DP;
+        if (g >= nhead || c >= d) continue;
+        float M = -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) M = fmaxf(M, red[ww][g][DP]);
+        float o = 0.f, L = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const float mw = red[ww][g][DP];
+            if (mw > -INFINITY) {
+                const float f = exp2f(mw - M);
+                o += f * red[ww][g][c];
+                L += f * red[ww][g][DP + 1];
+            }
+        }
+        out[(int64_t)bb * ld_out + (int64_t)(h0 + g) * d + c] = from_f32<T>(o / L);
+    }
+}
+
 template <typename T, int DP, int GH>
-__global__ void __launch_bounds__(256) attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kp, const T* __restrict__ vtp,
+__global__ void __launch_bounds__(512) attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kp, const T* __restrict__ vtp,
                                                           const T* __restrict__ kg, const T* __restrict__ vtg,
                                                           const int32_t* __restrict__ prompt_len, const int32_t* __restrict__ step_ptr,
                                                           int group, int nh, int nkv, int G, int Tp, int Gcap, float c_exp, int round_p,
-                                                          float* __restrict__ part, unsigned* __restrict__ counter, T* __restrict__ out,
-                                                          int64_t ld_out, int d) {
-    constexpr int PN = Piece<T>::N, R = DP > 64 ? DP / 64 : 1, PW = DP + 2;
+                                                          T* __restrict__ out, int64_t ld_out, int d) {
+    constexpr int PN = Piece<T>::N, R = DP > 64 ? DP / 64 : 1, PW = DP + 2, NW = 8;
     __shared__ float sq[GH][DP];
-    __shared__ float sp[4][GH][64];
-    __shared__ float red[4][GH][PW];
-    __shared__ int is_last;
+    __shared__ float sp[NW][GH][64];
+    __shared__ float red[NW][GH][PW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int pair = blockIdx.x, bb = pair / nkv, kvh = pair - bb * nkv, b0 = bb / group;
-    const int s = blockIdx.y, NS = gridDim.y, hc = blockIdx.z;
+    const int hc = blockIdx.y;
     const int h0 = kvh * G + hc * GH, nhead = min(GH, G - hc * GH);          // query heads h0 .. h0 + nhead - 1
-    for (int i = threadIdx.x; i < GH * DP; i += 256) {
+    for (int i = threadIdx.x; i < GH * DP; i += NW * 64) {
         const int g = i / DP, c = i - g * DP;
         sq[g][c] = g < nhead ? to_f32(q[((int64_t)bb * nh + h0 + g) * DP + c]) : 0.f;
     }
@@ -194,7 +216,7 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const T* __restrict__ 
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[g][r] = 0.f;
     }
-    for (int t = s * 4 + w; t < tiles; t += NS * 4) {
+    for (int t = w; t < tiles; t += NW) {
         const int sg = t >= tiles0, tt = sg ? t - tiles0 : t, n = sg ? n1 : n0, cap = sg ? Gcap : Tp;
         const int key = tt * 64 + lane;
         const bool valid = key < n, full = tt * 64 + 64 <= n;
@@ -261,65 +283,130 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const T* __restrict__ 
             if (lane + 64 * r < DP) red[w][g][lane + 64 * r] = acc[g][r];
     }
     __syncthreads();
-    // merge of the four waves: thread -> (head, feature); columns DP / DP + 1 carry the max / the sum
-    const int64_t slot = ((int64_t)pair * gridDim.z + hc) * NS + s;
-    float* mine = part + slot * GH * PW;
-    for (int i = threadIdx.x; i < GH * PW; i += 256) {
-        const int g = i / PW, c = i - g * PW;
-        float M = -INFINITY;
+    decode_merge<T, DP, GH, NW>(red, bb, h0, nhead, d, out, ld_out);
+}
+
+// bf16 form on the matrix pipe (`v_mfma_f32_16x16x32_bf16`, fragments straight from global memory -- no LDS staging, the step is a
+// stream).  Per wave and 64-key tile:
+//   S[key, head] = K . q^T: A = 16 keys x 32 features of K (a lane: 16 bytes of one key row), B = q (16 head slots, the group's G
+//     real heads first, zeros behind), so a lane holds 4 keys of ONE head slot -- the softmax statistics of a head live in the four
+//     lanes l, l + 16, l + 32, l + 48;
+//   the A rows of the sub-tiles are permuted (row 4 g + r of sub-tile t <-> key 32 (t / 2) + 8 g + 4 (t % 2) + r), so that the eight
+//     probabilities a lane holds after two sub-tiles are 8 CONSECUTIVE keys: exactly the B operand of
+//   O[feature, head] += V^T . P: A = 16 features x 32 keys of the transposed value segment (a lane: 16 bytes = 8 consecutive keys of
+//     one feature), no exchange between lanes anywhere.
+template <int DP, int GH, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_decode_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kp,
+                                                               const bf16_t* __restrict__ vtp, const bf16_t* __restrict__ kg,
+                                                               const bf16_t* __restrict__ vtg, const int32_t* __restrict__ prompt_len,
+                                                               const int32_t* __restrict__ step_ptr, int group, int nh, int nkv, int G, int Tp,
+                                                               int Gcap, float c_exp, bf16_t* __restrict__ out, int64_t ld_out, int d) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    constexpr int PW = DP + 2, KK = DP / 32, DT = DP / 16;
+    __shared__ float red[NW][GH][PW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int pair = blockIdx.x, bb = pair / nkv, kvh = pair - bb * nkv, b0 = bb / group;
+    const int hc = blockIdx.y;
+    const int h0 = kvh * G + hc * GH, nhead = min(GH, G - hc * GH);
+    const bf16x8 zero8 = {};
+    bf16x8 qf[KK];                                                  // B operand of S: head slot j, features 32 kk + 8 g ..
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) M = fmaxf(M, red[ww][g][DP]);
-        float o = 0.f;
-        if (c == DP) {
-            o = M;
-        } else if (M > -INFINITY) {
+    for (int kk = 0; kk < KK; ++kk)
+        qf[kk] = j < nhead ? *reinterpret_cast<const bf16x8*>(q + ((int64_t)bb * nh + h0 + j) * DP + 32 * kk + 8 * g) : zero8;
+    const int n0 = min(max(prompt_len[b0], 0), Tp), n1 = min(max(step_ptr[0], 0) + 1, Gcap);
+    const int tiles0 = (n0 + 63) >> 6, tiles = tiles0 + ((n1 + 63) >> 6);
+    const bf16_t* k_seg0 = kp + ((int64_t)b0 * nkv + kvh) * Tp * DP;
+    const bf16_t* k_seg1 = kg + ((int64_t)bb * nkv + kvh) * Gcap * DP;
+    const bf16_t* v_seg0 = vtp + ((int64_t)b0 * nkv + kvh) * DP * Tp;
+    const bf16_t* v_seg1 = vtg + ((int64_t)bb * nkv + kvh) * DP * Gcap;
+    // A rows of S: lane row i = j <-> key offset 8 (i / 4) + (i % 4) inside a 32-key half, + 4 for the odd sub-tile
+    const int krow = 8 * (j >> 2) + (j & 3);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[DT];
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const float mw = red[ww][g][DP];
-                if (mw > -INFINITY) o += exp2f(mw - M) * red[ww][g][c];
-            }
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = w; t < tiles; t += NW) {
+        const int sg = t >= tiles0, tt = sg ? t - tiles0 : t, n = sg ? n1 : n0, cap = sg ? Gcap : Tp;
+        const bool full = tt * 64 + 64 <= n;
+        const bf16_t* kb = (sg ? k_seg1 : k_seg0) + (int64_t)tt * 64 * DP + 8 * g;
+        const bf16_t* vb = (sg ? v_seg1 : v_seg0) + (int64_t)tt * 64 + 8 * g;
+        // all fragments of the tile first (32 loads of 16 bytes in flight per lane), then the arithmetic
+        bf16x8 kf[4][KK], vf[2][DT];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                kf[st][kk] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)(32 * (st >> 1) + 4 * (st & 1) + krow) * DP + 32 * kk);
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[hv][dt] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)(16 * dt + j) * cap + 32 * hv);
+        f32x4 sc[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            sc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) sc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[st][kk], qf[kk], sc[st], 0, 0, 0);
         }
-        if (NS > 1) {
-            mine[i] = o;
-        } else if (c < d && g < nhead) {
-            float L = 0.f;
+        // lane (head j, g): sc[st][r] is the key 32 (st / 2) + 8 g + 4 (st % 2) + r of the tile
+        float mx = -INFINITY;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const float mw = red[ww][g][DP];
-                if (mw > -INFINITY) L += exp2f(mw - M) * red[ww][g][DP + 1];
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = full || tt * 64 + 32 * (st >> 1) + 8 * g + 4 * (st & 1) + r < n;
+                sc[st][r] = ok ? sc[st][r] * c_exp : -INFINITY;
+                mx = fmaxf(mx, sc[st][r]);
             }
-            out[(int64_t)bb * ld_out + (int64_t)(h0 + g) * d + c] = from_f32<T>(o / L);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                          // every tile holds at least one valid key
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+            float p[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[e] = exp2f(sc[2 * hv + (e >> 2)][e & 3] - m_new);
+                psum += p[e];
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            pf[hv] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])});
+        }
+        l_run = l_run * alpha + psum;
+        if (!full) {                                                  // keys behind the valid prefix: 0 x garbage must stay 0
+#pragma unroll
+            for (int hv = 0; hv < 2; ++hv)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    s16x8 v = __builtin_bit_cast(s16x8, vf[hv][dt]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = tt * 64 + 32 * hv + 8 * g + e < n ? v[e] : (short)0;
+                    vf[hv][dt] = __builtin_bit_cast(bf16x8, v);
+                }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            acc[dt] *= alpha;
+#pragma unroll
+            for (int hv = 0; hv < 2; ++hv) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[hv][dt], pf[hv], acc[dt], 0, 0, 0);
         }
     }
-    if (NS == 1) return;
-    __threadfence();
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (j < GH) {                                                     // lane (head j, g) holds the features 16 dt + 4 g + r of its head
+        if (g == 0) { red[w][j][DP] = m_run; red[w][j][DP + 1] = l_run; }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][j][16 * dt + 4 * g + r] = acc[dt][r];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned ticket = atomicAdd(&counter[pair * gridDim.z + hc], 1u);
-        is_last = ticket == (unsigned)NS - 1;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const float* all = part + ((int64_t)pair * gridDim.z + hc) * NS * GH * PW;
-    for (int i = threadIdx.x; i < GH * DP; i += 256) {
-        const int g = i / DP, c = i - g * DP;
-        if (g >= nhead || c >= d) continue;
-        float M = -INFINITY;
-        for (int ss = 0; ss < NS; ++ss) M = fmaxf(M, all[((int64_t)ss * GH + g) * PW + DP]);
-        float o = 0.f, L = 0.f;
-        for (int ss = 0; ss < NS; ++ss) {
-            const float* p = all + ((int64_t)ss * GH + g) * PW;
-            const float ms = p[DP];
-            if (ms > -INFINITY) {
-                const float f = exp2f(ms - M);
-                o += f * p[c];
-                L += f * p[DP + 1];
-            }
-        }
-        out[(int64_t)bb * ld_out + (int64_t)(h0 + g) * d + c] = from_f32<T>(o / L);
-    }
-    if (threadIdx.x == 0) counter[pair * gridDim.z + hc] = 0;
+    decode_merge<bf16_t, DP, GH, NW>(red, bb, h0, nhead, d, out, ld_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -328,33 +415,41 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const T* __restrict__ 
 // torch.argmax semantics over the first V columns (lowest index among equal maxima), then HF's finished-row rule
 // (generation/utils.py, _sample: next = next * unfinished + pad * (1 - unfinished); a row finishes once it emits an eos id).
 template <typename T>
-__global__ void __launch_bounds__(256) greedy_select_kernel(const T* __restrict__ logits, int64_t ld, int V, const int64_t* __restrict__ eos,
-                                                            int n_eos, int64_t pad, int32_t* __restrict__ finished,
-                                                            int64_t* __restrict__ next, int64_t* __restrict__ out_tokens, int64_t ld_tok,
-                                                            const int32_t* __restrict__ step_ptr, int Gcap) {
-    __shared__ float bv[256];
-    __shared__ int bi[256];
-    const int bb = blockIdx.x, tid = threadIdx.x;
+__global__ void __launch_bounds__(1024) greedy_select_kernel(const T* __restrict__ logits, int64_t ld, int V, const int64_t* __restrict__ eos,
+                                                             int n_eos, int64_t pad, int32_t* __restrict__ finished,
+                                                             int64_t* __restrict__ next, int64_t* __restrict__ out_tokens, int64_t ld_tok,
+                                                             const int32_t* __restrict__ step_ptr, int Gcap) {
+    constexpr int PN = Piece<T>::N, kNone = 0x7fffffff;
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int bb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const T* row = logits + (int64_t)bb * ld;
     float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int c = tid; c < V; c += 256) {
-        const float v = to_f32(row[c]);
-        if (v > best || idx == 0x7fffffff) { best = v; idx = c; }
+    int idx = kNone;
+    auto take = [&](float v, int c) {                   // ascending c per thread: a later equal value never replaces an earlier one
+        if (idx == kNone || v > best) { best = v; idx = c; }
+    };
+    const int Vv = (ld % PN == 0) ? V / PN * PN : 0;     // 16-byte pieces while the row pitch keeps them aligned
+    for (int c = tid * PN; c < Vv; c += 1024 * PN) {
+        float v[PN];
+        load_piece<T, PN>(row + c, v);
+#pragma unroll
+        for (int e = 0; e < PN; ++e) take(v[e], c + e);
     }
-    bv[tid] = best;
-    bi[tid] = idx;
+    for (int c = Vv + tid; c < V; c += 1024) take(to_f32(row[c]), c);
+    auto better = [](float v, int i, float bvv, int bii) { return i != kNone && (bii == kNone || v > bvv || (v == bvv && i < bii)); };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(best, o, 64);
+        const int i2 = __shfl_xor(idx, o, 64);
+        if (better(v, i2, best, idx)) { best = v; idx = i2; }
+    }
+    if (lane == 0) { bv[w] = best; bi[w] = idx; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            const float v = bv[tid + o];
-            const int j = bi[tid + o];
-            if (j != 0x7fffffff && (bi[tid] == 0x7fffffff || v > bv[tid] || (v == bv[tid] && j < bi[tid]))) { bv[tid] = v; bi[tid] = j; }
-        }
-        __syncthreads();
-    }
     if (tid == 0) {
-        int64_t tok = bi[0];
+        for (int ww = 1; ww < 16; ++ww)
+            if (better(bv[ww], bi[ww], best, idx)) { best = bv[ww]; idx = bi[ww]; }
+        int64_t tok = idx;
         const int fin = finished[bb];
         if (fin) tok = pad;
         next[bb] = tok;
@@ -387,23 +482,17 @@ __global__ void __launch_bounds__(256) kv_reorder_kernel(const T* __restrict__ k
 __global__ void advance_kernel(int32_t* step) { step[0] += 1; }
 
 struct DecodeBuffers {
-    float* x; void* h; float* qkv; void* qb; void* ao; void* act; float* part; unsigned* counter; float* inv_freq;
-    int NS, ZC, GH;
+    float* x; void* h; float* qkv; void* qb; void* ao; void* act; float* inv_freq;
+    int ZC, GH;
 };
 
 int pick_gh(int G) { return G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8)); }
 
-// split-KV plan of attn_decode_kernel: GH query heads per block, ZC head chunks, NS key splits; -> floats of `part`
-size_t attn_decode_plan(int BB, int nh, int nkv, int dp, int Tp, int Gcap, int* NS, int* ZC, int* GH) {
+// GH query heads of a GQA group per block, ZC chunks of them (more than 8 heads per kv head: the keys are read once per chunk)
+void attn_decode_plan(int nh, int nkv, int* ZC, int* GH) {
     const int G = nh / nkv;
     *GH = pick_gh(G);
     *ZC = (G + *GH - 1) / *GH;
-    const int64_t max_tiles = (Tp + 63) / 64 + (Gcap + 63) / 64;
-    int64_t ns = ceil_div(2048, (int64_t)BB * nkv * *ZC * 4);               // about two waves per SIMD over the chip
-    ns = ns < 1 ? 1 : (ns > 32 ? 32 : ns);
-    const int64_t cap = ceil_div(max_tiles, 4);
-    *NS = (int)(ns > cap ? (cap < 1 ? 1 : cap) : ns);
-    return (size_t)BB * nkv * *ZC * *NS * *GH * (dp + 2);
 }
 
 size_t decode_plan(const p2t_llama_config* c, int BB, int Tp, int Gcap, Arena* ar, DecodeBuffers* b) {
@@ -414,15 +503,13 @@ size_t decode_plan(const p2t_llama_config* c, int BB, int Tp, int Gcap, Arena* a
     Arena local(nullptr, ~(size_t)0 >> 1);
     Arena& a = ar ? *ar : local;
     DecodeBuffers t;
-    const size_t part_floats = attn_decode_plan(BB, nh, nkv, dp, Tp, Gcap, &t.NS, &t.ZC, &t.GH);
+    attn_decode_plan(nh, nkv, &t.ZC, &t.GH);
     t.x = (float*)a.take(sizeof(float) * (size_t)BB * H);
     t.h = a.take(e * (size_t)BB * Hp);
     t.qkv = (float*)a.take(sizeof(float) * (size_t)BB * NQKV);
     t.qb = a.take(e * (size_t)BB * nh * dp);
     t.ao = a.take(e * (size_t)BB * QO);
     t.act = a.take(e * (size_t)BB * Fp);
-    t.part = (float*)a.take(sizeof(float) * part_floats);
-    t.counter = (unsigned*)a.take(sizeof(unsigned) * (size_t)BB * nkv * t.ZC);
     t.inv_freq = (float*)a.take(sizeof(float) * (d / 2 + 1));
     if (b) *b = t;
     return a.off + 256;
@@ -430,17 +517,34 @@ size_t decode_plan(const p2t_llama_config* c, int BB, int Tp, int Gcap, Arena* a
 
 template <typename T>
 int launch_attn_decode_t(const DecodeBuffers& b, const p2t_kv_cache* kc, int layer, int BB, int nh, int nkv, int d, int dp, float c_exp, int round_p,
-                         int64_t QO, hipStream_t s) {
+                         int64_t QO, hipStream_t s, int use_mfma = 1) {
     const int G = nh / nkv;
     const size_t per_p = (size_t)kc->B0 * nkv * kc->Tp * dp, per_g = (size_t)BB * nkv * kc->G * dp;
     const T* kp = (const T*)kc->k_prompt + per_p * layer;
     const T* vtp = (const T*)kc->vt_prompt + per_p * layer;
     const T* kg = (const T*)kc->k_gen + per_g * layer;
     const T* vtg = (const T*)kc->vt_gen + per_g * layer;
-    const dim3 grid((unsigned)(BB * nkv), (unsigned)b.NS, (unsigned)b.ZC);
+    const dim3 grid((unsigned)(BB * nkv), (unsigned)b.ZC);
+    if constexpr (sizeof(T) == 2) {
+        if (use_mfma) {                      // (0: the lane-per-key kernel below, the form every dtype can run)
+#define P2T_ADM(DPV, GHV)                                                                                                             \
+    attn_decode_mfma_kernel<DPV, GHV, (GHV <= 4 && DPV <= 64 ? 16 : 8)><<<grid, (GHV <= 4 && DPV <= 64 ? 16 : 8) * 64, 0, s>>>(                                  \
+        (const bf16_t*)b.qb, (const bf16_t*)kp, (const bf16_t*)vtp, (const bf16_t*)kg, (const bf16_t*)vtg, kc->prompt_len, kc->step, kc->group, nh, \
+        nkv, G, kc->Tp, kc->G, c_exp, (bf16_t*)b.ao, QO, d)
+#define P2T_ADM_G(DPV)                                                                                                                \
+    do {                                                                                                                              \
+        if (b.GH == 1) P2T_ADM(DPV, 1); else if (b.GH == 2) P2T_ADM(DPV, 2); else if (b.GH == 4) P2T_ADM(DPV, 4); else P2T_ADM(DPV, 8);  \
+    } while (0)
+            if (dp == 32) P2T_ADM_G(32); else if (dp == 64) P2T_ADM_G(64); else P2T_ADM_G(128);
+#undef P2T_ADM_G
+#undef P2T_ADM
+            P2T_LAUNCH_CHECK();
+            return P2T_OK;
+        }
+    }
 #define P2T_AD(DPV, GHV)                                                                                                              \
-    attn_decode_kernel<T, DPV, GHV><<<grid, 256, 0, s>>>((const T*)b.qb, kp, vtp, kg, vtg, kc->prompt_len, kc->step, kc->group, nh, nkv, G, \
-                                                         kc->Tp, kc->G, c_exp, round_p, b.part, b.counter, (T*)b.ao, QO, d)
+    attn_decode_kernel<T, DPV, GHV><<<grid, 512, 0, s>>>((const T*)b.qb, kp, vtp, kg, vtg, kc->prompt_len, kc->step, kc->group, nh, nkv, G, \
+                                                         kc->Tp, kc->G, c_exp, round_p, (T*)b.ao, QO, d)
 #define P2T_AD_G(DPV)                                                                                                                 \
     do {                                                                                                                              \
         if (b.GH == 1) P2T_AD(DPV, 1); else if (b.GH == 2) P2T_AD(DPV, 2); else if (b.GH == 4) P2T_AD(DPV, 4); else P2T_AD(DPV, 8);      \
@@ -524,8 +628,8 @@ extern "C" size_t p2t_llama_decode_workspace_bytes(const p2t_llama_config* cfg, 
     return decode_plan(cfg, BB, Tp, G, nullptr, nullptr);
 }
 
-extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_weights* w, const void* lm_head, int64_t ld_head,
-                                     const p2t_kv_cache* cache, const float* x_in, void* logits, int64_t ld_logits, void* workspace,
+extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_weights* w, const p2t_llama_layer_stream* ws_layers,
+                                     const void* lm_head, int64_t ld_head, int lm_head_preshuffled, const p2t_kv_cache* cache, const float* x_in, void* logits, int64_t ld_logits, void* workspace,
                                      size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(c && w && w->layers && w->final_norm_w && lm_head && x_in && logits && workspace, "p2t_llama_decode_step: null argument");
     P2T_TRY(check_cache(c, cache, "p2t_llama_decode_step"));
@@ -535,7 +639,7 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
     const int64_t H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
     const int d = c->head_dim, dp = head_dim_padded(d), nh = c->heads, nkv = c->kv_heads;
     const int64_t NQKV = (int64_t)(nh + 2 * nkv) * d, QO = round_up((int64_t)nh * d, 64);
-    P2T_REQUIRE(ld_head >= Hp && ld_logits >= c->vocab, "p2t_llama_decode_step: ld_head %lld < %lld or ld_logits %lld < vocab", (long long)ld_head,
+    P2T_REQUIRE((lm_head_preshuffled || ld_head >= Hp) && ld_logits >= c->vocab, "p2t_llama_decode_step: ld_head %lld < %lld or ld_logits %lld < vocab", (long long)ld_head,
                 (long long)Hp, (long long)ld_logits);
     P2T_REQUIRE(workspace_bytes >= decode_plan(c, BB, cache->Tp, cache->G, nullptr, nullptr), "p2t_llama_decode_step: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -553,16 +657,22 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
     const int l2s = dt == P2T_BF16;                      // as the prefill: scale * log2(e) folded into q for bf16 models
     const float q_fold = l2s ? scale * kLog2e : 1.0f, c_exp = l2s ? 1.0f : scale * kLog2e;
     P2T_CHECK_HIP(hipMemcpyAsync(b.x, x_in, sizeof(float) * (size_t)BB * H, hipMemcpyDeviceToDevice, s));
-    P2T_CHECK_HIP(hipMemsetAsync(b.counter, 0, sizeof(unsigned) * (size_t)BB * nkv * b.ZC, s));
     P2T_CHECK_HIP(hipMemsetAsync(b.ao, 0, dtype_size(dt) * (size_t)BB * QO, s));
     const int64_t M = BB;
+    // the step's projections: the weight-streaming kernel (gemm_skinny.hip) for bf16 models, the general GEMM otherwise
+    // `pre`: the pre-shuffled stream copy of the same weight (p2t_preshuffle_w), when the caller built one
+    auto gemm_nt = [&](const GemmArgs& a, hipStream_t st, const void* pre = nullptr) {
+        const int r = launch_gemm_skinny(a.A, a.lda, pre ? pre : a.W, a.ldw, a.out, a.ldc, a.M, a.N, a.K, a.dtype, a.out_dtype, a.epilogue, st, pre != nullptr);
+        return r == P2T_ERR_UNSUPPORTED ? p2t::gemm_nt(a, st) : r;
+    };
+    const bool stream_w = ws_layers && dt == P2T_BF16;
     for (int l = 0; l < c->n_layers; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_decode_step: q_norm_w and k_norm_w go together (layer %d)", l);
         const int fused_prefill = !L.q_norm_w && (d == 64 || d == 128);
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
         GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, P2T_F32, P2T_EPI_STORE_F32, 0, -1, (int)NQKV, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g1, s));
+        P2T_TRY(gemm_nt(g1, s, stream_w ? ws_layers[l].qkv_w : nullptr));
         {
             const unsigned grid = (unsigned)ceil_div((int64_t)BB * (nh + 2 * nkv), 4);
             const size_t per_g = (size_t)BB * nkv * cache->G * dp;
@@ -581,16 +691,17 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
         if (dt == P2T_BF16) P2T_TRY(launch_attn_decode_t<bf16_t>(b, cache, l, BB, nh, nkv, d, dp, c_exp, 1, QO, s));
         else P2T_TRY(launch_attn_decode_t<float>(b, cache, l, BB, nh, nkv, d, dp, c_exp, 0, QO, s));
         GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g2, s));
+        P2T_TRY(gemm_nt(g2, s, stream_w ? ws_layers[l].o_w : nullptr));
         P2T_TRY(launch_rmsnorm(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
         GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, b.act, Fp, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_SWIGLU, 0, -1, -1, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g3, s));
+        P2T_TRY(gemm_nt(g3, s, stream_w ? ws_layers[l].gu_w : nullptr));
         GemmArgs g4{b.act, Fp, L.down_w, Fp, nullptr, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g4, s));
+        P2T_TRY(gemm_nt(g4, s, stream_w ? ws_layers[l].down_w : nullptr));
     }
     P2T_TRY(launch_rmsnorm(b.x, H, w->final_norm_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
+    P2T_REQUIRE(!lm_head_preshuffled || dt == P2T_BF16, "p2t_llama_decode_step: pre-shuffled weights are a bf16 layout");
     GemmArgs gh{b.h, Hp, lm_head, ld_head, nullptr, logits, ld_logits, nullptr, M, c->vocab, Hp, dt, dt, P2T_EPI_STORE, 0, -1, -1, 0.f, 0, 0};
-    P2T_TRY(gemm_nt(gh, s));
+    P2T_TRY(gemm_nt(gh, s, lm_head_preshuffled ? lm_head : nullptr));
     advance_kernel<<<1, 1, 0, s>>>(cache->step);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
@@ -604,10 +715,10 @@ extern "C" int p2t_greedy_select(const void* logits, int dtype, int64_t ld, int 
                 "p2t_greedy_select: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == P2T_BF16)
-        greedy_select_kernel<bf16_t><<<BB, 256, 0, s>>>((const bf16_t*)logits, ld, V, eos_ids, n_eos, pad_id, finished, next_tokens, out_tokens,
+        greedy_select_kernel<bf16_t><<<BB, 1024, 0, s>>>((const bf16_t*)logits, ld, V, eos_ids, n_eos, pad_id, finished, next_tokens, out_tokens,
                                                         ld_tokens, step, G);
     else
-        greedy_select_kernel<float><<<BB, 256, 0, s>>>((const float*)logits, ld, V, eos_ids, n_eos, pad_id, finished, next_tokens, out_tokens,
+        greedy_select_kernel<float><<<BB, 1024, 0, s>>>((const float*)logits, ld, V, eos_ids, n_eos, pad_id, finished, next_tokens, out_tokens,
                                                        ld_tokens, step, G);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
@@ -631,36 +742,24 @@ extern "C" int p2t_kv_reorder(const p2t_llama_config* c, const p2t_kv_cache* cac
     return P2T_OK;
 }
 
-extern "C" size_t p2t_attention_decode_workspace_bytes(int B0, int group, int nh, int nkv, int head_dim, int Tp, int G) {
-    if (B0 <= 0 || group <= 0 || nh <= 0 || nkv <= 0 || nh % nkv || head_dim <= 0 || head_dim > 128 || Tp <= 0 || G <= 0) return 0;
-    int NS, ZC, GH;
-    const size_t f = attn_decode_plan(B0 * group, nh, nkv, head_dim_padded(head_dim), Tp, G, &NS, &ZC, &GH);
-    return sizeof(float) * f + sizeof(unsigned) * (size_t)B0 * group * nkv * ZC + 512;
-}
-
 extern "C" int p2t_attention_decode(const void* q, const void* k_prompt, const void* vt_prompt, const void* k_gen, const void* vt_gen,
                                     const int32_t* prompt_len, const int32_t* step, int B0, int group, int nh, int nkv, int head_dim, int Tp, int G,
-                                    float scale, int log2_scores, int dtype, void* out, int64_t ld_out, void* workspace, size_t workspace_bytes,
-                                    p2t_stream stream) {
-    P2T_REQUIRE(q && out && workspace && (dtype == P2T_F32 || dtype == P2T_BF16) && nkv > 0 && nh % nkv == 0 && ld_out >= (int64_t)nh * head_dim,
+                                    float scale, int log2_scores, int dtype, int use_mfma, void* out, int64_t ld_out, p2t_stream stream) {
+    P2T_REQUIRE(q && out && (dtype == P2T_F32 || dtype == P2T_BF16) && nkv > 0 && nh % nkv == 0 && ld_out >= (int64_t)nh * head_dim,
                 "p2t_attention_decode: bad arguments");
     p2t_llama_config c{};
     c.heads = nh; c.kv_heads = nkv; c.head_dim = head_dim; c.dtype = dtype;
     p2t_kv_cache kc{const_cast<void*>(k_prompt), const_cast<void*>(vt_prompt), const_cast<void*>(k_gen), const_cast<void*>(vt_gen), prompt_len,
                     const_cast<int32_t*>(step), B0, group, Tp, G};
     P2T_TRY(check_cache(&c, &kc, "p2t_attention_decode"));
-    P2T_REQUIRE(workspace_bytes >= p2t_attention_decode_workspace_bytes(B0, group, nh, nkv, head_dim, Tp, G), "p2t_attention_decode: workspace too small");
     const int BB = B0 * group, dp = head_dim_padded(head_dim);
     DecodeBuffers b{};
-    const size_t f = attn_decode_plan(BB, nh, nkv, dp, Tp, G, &b.NS, &b.ZC, &b.GH);
-    Arena ar(workspace, workspace_bytes);
-    b.part = (float*)ar.take(sizeof(float) * f);
-    b.counter = (unsigned*)ar.take(sizeof(unsigned) * (size_t)BB * nkv * b.ZC);
+    attn_decode_plan(nh, nkv, &b.ZC, &b.GH);
     b.qb = const_cast<void*>(q);
     b.ao = out;
     hipStream_t s = (hipStream_t)stream;
-    P2T_CHECK_HIP(hipMemsetAsync(b.counter, 0, sizeof(unsigned) * (size_t)BB * nkv * b.ZC, s));
     const float c_exp = log2_scores ? 1.0f : scale * kLog2e;
-    if (dtype == P2T_BF16) return launch_attn_decode_t<bf16_t>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 1, ld_out, s);
+    if (dtype == P2T_BF16) return launch_attn_decode_t<bf16_t>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 1, ld_out, s, use_mfma != 0);
+    P2T_REQUIRE(use_mfma <= 0, "p2t_attention_decode: the matrix-pipe kernel is bf16 only");
     return launch_attn_decode_t<float>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 0, ld_out, s);
 }

@@ -200,6 +200,7 @@ extern "C" size_t p2t_struct_size(int which) {
         case 8: return sizeof(p2t_adapter_saved);
         case 9: return sizeof(p2t_llama_layer_t);
         case 10: return sizeof(p2t_kv_cache);
+        case 11: return sizeof(p2t_llama_layer_stream);
     }
     return 0;
 }

@@ -87,8 +87,12 @@ class KvCacheC(C.Structure):
                 ("B0", C.c_int32), ("group", C.c_int32), ("Tp", C.c_int32), ("G", C.c_int32)]
 
 
+class LlamaLayerStreamC(C.Structure):
+    _fields_ = [(n, vp) for n in ("qkv_w", "o_w", "gu_w", "down_w")]
+
+
 _STRUCTS = [EsmConfigC, EsmLayerC, EsmWeightsC, LlamaConfigC, LlamaLayerC, LlamaWeightsC, AdapterConfigC,
-            AdapterWeightsC, AdapterSavedC, LlamaLayerTC, KvCacheC]
+            AdapterWeightsC, AdapterSavedC, LlamaLayerTC, KvCacheC, LlamaLayerStreamC]
 
 # name -> (restype, argtypes); every symbol include/p2t_hip.h declares
 SIGNATURES = {
@@ -127,10 +131,12 @@ SIGNATURES = {
     "p2t_llama_prefill_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
     "p2t_llama_prefill": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, vp, i32, i32, C.POINTER(KvCacheC), vp, vp, sz, vp]),
     "p2t_llama_decode_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32, i32]),
-    "p2t_llama_decode_step": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, i64, C.POINTER(KvCacheC), vp, vp, i64, vp, sz, vp]),
+    "p2t_llama_decode_step": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), C.POINTER(LlamaLayerStreamC), vp, i64, i32, C.POINTER(KvCacheC), vp, vp, i64,
+                              vp, sz, vp]),
     "p2t_greedy_select": (i32, [vp, i32, i64, i32, i32, vp, i32, i64, vp, vp, vp, i64, vp, i32, vp]),
-    "p2t_attention_decode_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
-    "p2t_attention_decode": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, i64, vp, sz, vp]),
+    "p2t_attention_decode": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp, i64, vp]),
+    "p2t_gemm_nt_skinny": (i32, [vp, i64, vp, i64, i32, vp, i64, i64, i64, i64, i32, i32, vp]),
+    "p2t_preshuffle_w": (i32, [vp, i64, i64, i64, vp, vp]),
     "p2t_kv_reorder": (i32, [C.POINTER(LlamaConfigC), C.POINTER(KvCacheC), vp, vp, vp, vp]),
     "p2t_llama_tape_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
     "p2t_llama_train_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
@@ -177,7 +183,7 @@ for _i, _s in enumerate(_STRUCTS):
     if lib.p2t_struct_size(_i) != C.sizeof(_s):
         raise ImportError(f"ABI mismatch: {_s.__name__} is {C.sizeof(_s)} bytes here, {lib.p2t_struct_size(_i)} in the library")
 
-_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_is_lab_build", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes", "p2t_llama_tape_bytes", "p2t_llama_train_workspace_bytes", "p2t_llama_prefill_workspace_bytes", "p2t_llama_decode_workspace_bytes", "p2t_attention_decode_workspace_bytes",
+_NO_RC = {"p2t_gemm_fix_workspace_bytes", "p2t_version", "p2t_is_lab_build", "p2t_last_error", "p2t_struct_size", "p2t_esm2_workspace_bytes", "p2t_llama_workspace_bytes", "p2t_llama_tape_bytes", "p2t_llama_train_workspace_bytes", "p2t_llama_prefill_workspace_bytes", "p2t_llama_decode_workspace_bytes",
           "p2t_adapter_backward_workspace_bytes"}
 
 

@@ -73,10 +73,42 @@ def filter_logits(scores: torch.Tensor, temperature: float = 1.0, top_k: Optiona
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+def preshuffle(w: torch.Tensor, n: int) -> torch.Tensor:
+    """bf16 [>= n, K] -> the stream order of the decode GEMM (p2t_preshuffle_w): 1 KB per (16 rows, 32 of K), whole-line loads."""
+    K = w.shape[1]
+    out = torch.empty((round_up(n, 16) * K,), dtype=torch.bfloat16, device=w.device)
+    call("p2t_preshuffle_w", ptr(w), w.stride(0), n, K, ptr(out), stream())
+    return out
+
+
+def stream_weights(decoder):
+    """Second copies of every decoder projection + the LM head in the stream order, built once per model (dropped with the engine
+    when weights are loaded): Llama-3.1-8B: 15 GB next to the 15 GB the prefill reads -- HBM is sized for it."""
+    m, s = decoder.model, decoder.spec
+    e = m.ensure_engine(s.num_hidden_layers)
+    lm = decoder._lm_head_padded()
+    key = (id(e), lm.data_ptr())
+    st = getattr(m, "_stream_engine", None)
+    if st is not None and st["key"] == key:
+        return st
+    d, nh, nkv = s.head_dim, s.num_attention_heads, s.num_key_value_heads
+    rows = dict(qkv_w=(nh + 2 * nkv) * d, o_w=s.hidden_size, gu_w=2 * s.intermediate_size, down_w=s.hidden_size)
+    layers, keep = (_lib.LlamaLayerStreamC * s.num_hidden_layers)(), []
+    for i in range(s.num_hidden_layers):
+        t = e["keep"][i]
+        for name, n in rows.items():
+            w = preshuffle(t[name], n)
+            keep.append(w)
+            setattr(layers[i], name, w.data_ptr())
+    st = dict(key=key, layers=layers, keep=keep, lm_head=preshuffle(lm, s.vocab_size))
+    m._stream_engine = st
+    return st
+
+
 class DecodeEngine:
     """Cache + buffers of ONE generate() call: B0 prompts, `group` rows per prompt (beams), capacities Tp / G (multiples of 64)."""
 
-    def __init__(self, decoder, B0: int, group: int, T: int, max_new_tokens: int):
+    def __init__(self, decoder, B0: int, group: int, T: int, max_new_tokens: int, stream_copy: bool = True):
         m, s = decoder.model, decoder.spec
         if m.gemm_fp8:
             raise ValueError("generation runs the decoder GEMMs in the model dtype: call set_gemm_dtype('model') first")
@@ -103,6 +135,7 @@ class DecodeEngine:
         self.ws = torch.empty((call("p2t_llama_decode_workspace_bytes", C.byref(self.e["cfg"]), self.BB, self.Tp, self.G),), dtype=torch.uint8,
                               device=self.dev)
         self.lm_head = decoder._lm_head_padded()
+        self.stream = stream_weights(decoder) if (stream_copy and self.dtype == torch.bfloat16) else None
         self._cache_struct()
 
     def _cache_struct(self):
@@ -144,8 +177,11 @@ class DecodeEngine:
 
     def decode_step(self):
         """One token per row from self.x -> self.logits; the device step counter advances."""
-        call("p2t_llama_decode_step", C.byref(self.e["cfg"]), C.byref(self.e["w"]), ptr(self.lm_head), self.lm_head.stride(0), C.byref(self.cache),
-             ptr(self.x), ptr(self.logits), self.ld_logits, ptr(self.ws), self.ws.numel(), stream())
+        st = self.stream
+        layers = C.cast(st["layers"], C.POINTER(_lib.LlamaLayerStreamC)) if st else None
+        head = st["lm_head"] if st else self.lm_head
+        call("p2t_llama_decode_step", C.byref(self.e["cfg"]), C.byref(self.e["w"]), layers, ptr(head), self.lm_head.stride(0), int(st is not None),
+             C.byref(self.cache), ptr(self.x), ptr(self.logits), self.ld_logits, ptr(self.ws), self.ws.numel(), stream())
 
     def greedy_select(self, logits: torch.Tensor, eos: torch.Tensor, pad_id: int):
         call("p2t_greedy_select", ptr(logits), ops.dt_of(logits), logits.stride(0), self.spec.vocab_size, self.BB, ptr(eos) if eos.numel() else None,
@@ -180,7 +216,7 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
              top_k: Optional[int] = 50, top_p: Optional[float] = 1.0, num_beams: int = 1, length_penalty: float = 1.0,
              early_stopping=False, num_return_sequences: int = 1, return_dict_in_generate: bool = False, output_scores: bool = False,
              output_logits: bool = False, use_graph: bool = True, sync_every: int = 16, generator: Optional[torch.Generator] = None,
-             **unused):
+             stream_copy: bool = True, **unused):
     """`LlamaForCausalLM.generate` for prompts given as embeddings (or ids): greedy, sampling (temperature / top-k / top-p) and beam
     search with length penalty.  Returns the new token ids i64 [batch * num_return_sequences, n] (or a GenerateOutput)."""
     if (inputs_embeds is None) == (input_ids is None):
@@ -216,11 +252,11 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
         if do_sample:
             raise NotImplementedError("beam sampling (num_beams > 1 with do_sample=True) is not built")
         return _beam_search(decoder, inputs_embeds, attention_mask, max_new_tokens, eos_ids, int(pad_token_id), num_beams, float(length_penalty),
-                            early_stopping, num_return_sequences, return_dict_in_generate, output_scores, output_logits)
+                            early_stopping, num_return_sequences, return_dict_in_generate, output_scores, output_logits, stream_copy)
     if num_return_sequences != 1:
         raise NotImplementedError("num_return_sequences > 1 needs num_beams > 1")
 
-    eng = DecodeEngine(decoder, B, 1, T, max_new_tokens)
+    eng = DecodeEngine(decoder, B, 1, T, max_new_tokens, stream_copy)
     embeds, mask = eng.compact(inputs_embeds, attention_mask)
     logits = eng.prefill(embeds, mask)
     V = decoder.spec.vocab_size
@@ -283,9 +319,9 @@ def _gather_beams(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 def _beam_search(decoder, inputs_embeds, attention_mask, max_length: int, eos_ids, pad_id: int, nb: int, length_penalty: float, early_stopping,
-                 num_return_sequences: int, return_dict: bool, output_scores: bool, output_logits: bool):
+                 num_return_sequences: int, return_dict: bool, output_scores: bool, output_logits: bool, stream_copy: bool = True):
     B = inputs_embeds.shape[0]
-    eng = DecodeEngine(decoder, B, nb, inputs_embeds.shape[1], max_length)
+    eng = DecodeEngine(decoder, B, nb, inputs_embeds.shape[1], max_length, stream_copy)
     dev, V = eng.dev, decoder.spec.vocab_size
     embeds, mask = eng.compact(inputs_embeds, attention_mask)
     first_logits = eng.prefill(embeds, mask)                                 # [B, ld]: the beams of a prompt start from the same state

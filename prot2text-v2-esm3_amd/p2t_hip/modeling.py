@@ -415,6 +415,7 @@ class LlamaTextModel(nn.Module):
     def invalidate_engine(self):
         self._engine = None
         self._train_engine = None
+        self._stream_engine = None          # generation.stream_weights
 
     def _build_engine(self, n_layers: int):
         s, dt = self.spec, self.dtype

@@ -90,10 +90,10 @@ def _attn_ref(q, kp, vp, kg, vg, lens, step, group, scale):
     return out
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt,use_mfma", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("shape", [(16, 4, 2, 1, 100, 3), (64, 4, 2, 2, 700, 70), (128, 8, 2, 1, 1500, 130), (48, 5, 1, 3, 64, 0),
                                    (128, 2, 2, 1, 5, 63), (64, 16, 1, 1, 200, 9)])
-def test_decode_attention_vs_numpy(dt, shape):
+def test_decode_attention_vs_numpy(dt, use_mfma, shape):
     """p2t_attention_decode (the decode step's attention on its own) against softmax(q k^T) v over the concatenated valid keys; NaN
     behind every valid prefix proves nothing outside it is read into a result."""
     from p2t_hip import _lib, ops
@@ -121,9 +121,8 @@ def test_decode_attention_vs_numpy(dt, shape):
     l2s = dt == torch.bfloat16
     QO = ops.round_up(nh * d, 64)
     out = torch.zeros((BB, QO), dtype=dt, device=dev())
-    ws = torch.empty((_lib.call("p2t_attention_decode_workspace_bytes", B0, group, nh, nkv, d, Tp, G),), dtype=torch.uint8, device=dev())
     _lib.call("p2t_attention_decode", ptr(qd), ptr(kpd), ptr(vtp), ptr(kgd), ptr(vtg), ptr(lens_d), ptr(step_d), B0, group, nh, nkv, d, Tp, G,
-              float(scale), int(l2s), ops.dt_of(dt), ptr(out), QO, ptr(ws), ws.numel(), stream())
+              float(scale), int(l2s), ops.dt_of(dt), use_mfma, ptr(out), QO, stream())
     qq = rd(pad(q))[..., :d]
     ref = _attn_ref(qq, np.nan_to_num(rd(pad(kp)))[..., :d], np.nan_to_num(rd(pad(vp)))[..., :d], np.nan_to_num(rd(pad(kg)))[..., :d],
                     np.nan_to_num(rd(pad(vg)))[..., :d], lens, step, group, (np.log(2.0) if l2s else scale))
@@ -132,7 +131,51 @@ def test_decode_attention_vs_numpy(dt, shape):
     if dt == torch.float32:
         assert rel(got, ref) < 3e-6
     else:
-        observe(f"decode_attn[d{d},nh{nh},nkv{nkv},g{group},n{n0max},s{step}].bf16", rel(got, ref), 1.2e-2)
+        observe(f"decode_attn[d{d},nh{nh},nkv{nkv},g{group},n{n0max},s{step}].bf16{'_mfma' if use_mfma else ''}", rel(got, ref), 1.2e-2)
+
+
+@pytest.mark.parametrize("shape", [(1, 512, 64), (3, 48, 96), (8, 4096, 4096), (16, 6144, 4096), (17, 1000, 512), (32, 28672, 1024), (40, 4096, 14336),
+                                   (64, 33000, 256)])
+def test_skinny_gemm_vs_numpy(shape):
+    """p2t_gemm_nt_skinny (the decode step's weight-streaming GEMM) against numpy on the same bf16 operands: f32 store, bf16 store,
+    residual accumulate, SwiGLU over the gate/up interleave; row counts 1..64, ragged N, K down to two MFMA steps."""
+    from p2t_hip import _lib
+    from p2t_hip.ops import ptr, stream
+    M, N, K = shape
+    bf = lambda a: to_np(to_dev(a, torch.bfloat16)).astype(np.float32)
+    x, w = bf(rnd(7, "sk.x", (M, K), 2.0)), bf(rnd(7, "sk.w", (N, K), 2.0 / np.sqrt(K)))
+    xd, wd = to_dev(x, torch.bfloat16), to_dev(w, torch.bfloat16)
+    ref = x @ w.T
+    ldc = (N + 3) // 4 * 4
+    out = torch.full((M, ldc), 7.0, dtype=torch.float32, device=dev())
+    _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(wd), K, 0, ptr(out), ldc, M, N, K, _lib.F32, _lib.EPI_STORE, stream())
+    assert rel(to_np(out)[:, :N], ref) < 3e-6 and (to_np(out)[:, N:] == 7.0).all()
+    # the same product from the pre-shuffled stream copy of W: bit-identical (same fragments, same order)
+    from p2t_hip.generation import preshuffle
+    ws = preshuffle(wd, N)
+    out2 = torch.full((M, ldc), 7.0, dtype=torch.float32, device=dev())
+    _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(ws), 0, 1, ptr(out2), ldc, M, N, K, _lib.F32, _lib.EPI_STORE, stream())
+    assert torch.equal(out, out2)
+    base = rnd(7, "sk.r", (M, ldc), 1.0)
+    acc = to_dev(base.copy())
+    _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(ws), 0, 1, ptr(acc), ldc, M, N, K, _lib.F32, _lib.EPI_RESID, stream())
+    assert rel(to_np(acc)[:, :N], base[:, :N] + ref) < 3e-6
+    ob = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())
+    _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(wd), K, 0, ptr(ob), ldc, M, N, K, _lib.BF16, _lib.EPI_STORE, stream())
+    assert np.array_equal(to_np(ob).astype(np.float32)[:, :N], bf(to_np(out)[:, :N]))       # the same accumulators, rounded once
+    if N % 64 == 0:
+        F = N // 2
+        blocks = ref.reshape(M, N // 64, 2, 32)                       # 32-row gate / up blocks of p2t_llama_layer.gu_w
+        gate, up = blocks[:, :, 0].reshape(M, F), blocks[:, :, 1].reshape(M, F)
+        act = torch.zeros((M, F), dtype=torch.bfloat16, device=dev())
+        _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(wd), K, 0, ptr(act), F, M, N, K, _lib.BF16, _lib.EPI_SWIGLU, stream())
+        act2 = torch.zeros((M, F), dtype=torch.bfloat16, device=dev())
+        _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(ws), 0, 1, ptr(act2), F, M, N, K, _lib.BF16, _lib.EPI_SWIGLU, stream())
+        assert torch.equal(act, act2)
+        want = gate / (1.0 + np.exp(-gate)) * up
+        assert rel(to_np(act).astype(np.float32), want) < 4e-3
+    with pytest.raises(_lib.P2TError):
+        _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(wd), K, 0, ptr(out), ldc, 65, N, K, _lib.F32, _lib.EPI_STORE, stream())
 
 
 def test_greedy_select_ties_and_finished_rows():
@@ -200,6 +243,10 @@ def test_bf16_steps_vs_bf16_oracle_and_own_forward(g, case):
     out = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True,
                          output_logits=True)
     toks, lg = to_np(out.sequences), to_np(torch.stack(out.logits, 0))
+    # the decoder streamed from its own matrices instead of the pre-shuffled copies: the same fragments in the same order
+    out_n = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True,
+                           output_logits=True, stream_copy=False)
+    assert torch.equal(out.sequences, out_n.sequences) and torch.equal(torch.stack(out.logits, 0), torch.stack(out_n.logits, 0))
     esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
     W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
     emb, mask = model(input_ids=to_dev(g["input_ids"]), attention_mask=to_dev(g["attention_mask"]), protein_input_ids=to_dev(g["protein_input_ids"]),

@@ -204,6 +204,41 @@ def bench_fp8():
               f"{res[3] * 1e3:6.1f} us {M * K * 3 / res[3] / 1e6:6.0f} GB/s | four-wave persistent {res[4] * 1e3:7.1f} us {fl / res[4]:7.1f}", flush=True)
 
 
+def bench_skinny():
+    """The decode step's weight-streaming GEMM (p2t_gemm_nt_skinny) on the Llama-3.1-8B projections: every call reads another copy
+    of the weights (a ring of copies > 1 GB, so neither the L2s nor the 256 MB memory-side cache serve them) -> GB/s of W."""
+    from p2t_hip.ops import ptr, stream
+    shapes = [("o-proj", 4096, 4096, _lib.EPI_RESID), ("qkv", 6144, 4096, _lib.EPI_STORE_F32), ("gate/up", 28672, 4096, _lib.EPI_SWIGLU),
+              ("down", 4096, 14336, _lib.EPI_RESID), ("lm head", 128256, 4096, _lib.EPI_STORE)]
+    Ms = [int(a[1:]) for a in sys.argv if a.startswith("m") and a[1:].isdigit()] or [8, 32]
+    for M in Ms:
+        for name, N, K, epi in shapes:
+            copies = max(2, min(40, int(1.3e9 // (N * K * 2)) + 1))
+            ws = [rand((N, K), scale=0.02) for _ in range(copies)]
+            x = rand((M, K))
+            if epi == _lib.EPI_SWIGLU:
+                out, ldc, odt = torch.zeros((M, N // 2), dtype=torch.bfloat16, device=dev), N // 2, _lib.BF16
+            elif epi == _lib.EPI_STORE:
+                out, ldc, odt = torch.zeros((M, N), dtype=torch.bfloat16, device=dev), N, _lib.BF16
+            else:
+                out, ldc, odt = torch.zeros((M, N), dtype=torch.float32, device=dev), N, _lib.F32
+            from p2t_hip.generation import preshuffle
+            res = []
+            for pre in (0, 1):
+                if pre:
+                    ws = [preshuffle(w, N) for w in ws]
+                i = [0]
+
+                def run():
+                    w = ws[i[0] % copies]
+                    i[0] += 1
+                    _lib.call("p2t_gemm_nt_skinny", ptr(x), K, ptr(w), K, pre, ptr(out), ldc, M, N, K, odt, epi, stream())
+                ms = timeit(run, iters=max(20, copies), warm=copies)
+                res.append(f"{'stream copy' if pre else 'row-major W'} {ms * 1e3:7.1f} us {N * K * 2 / ms / 1e6:6.0f} GB/s")
+            print(f"skinny M={M:2d} {name:8s} N={N:6d} K={K:5d}: " + " | ".join(res), flush=True)
+            del ws
+
+
 def bench_fp8abl():
     """Lab ablations of the fp8 K loop (per-tile kernel, garbage results): full / no DMA / no fragment reloads / neither."""
     for name, M, N, K in (("esm qkv b64", 65536, 7680, 2560), ("esm fc2 b64", 65536, 2560, 10240), ("square 8k", 8192, 8192, 8192)):
@@ -232,5 +267,7 @@ if __name__ == "__main__":
         bench_blas()
     if "fp8" in which:
         bench_fp8()
+    if "skinny" in which:
+        bench_skinny()
     if "fp8abl" in which:
         bench_fp8abl()
