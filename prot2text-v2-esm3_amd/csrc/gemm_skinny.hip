@@ -18,7 +18,7 @@ namespace p2t {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-enum { SK_STORE = 0, SK_STORE_F32 = 1, SK_RESID = 2, SK_SWIGLU = 3 };
+enum { SK_STORE = 0, SK_STORE_F32 = 1, SK_RESID = 2, SK_SWIGLU = 3, SK_QKV_ROPE = 4 };
 constexpr int kSkWaves = 8;
 
 __device__ __forceinline__ bf16x8 ld_stream(const bf16_t* p) {
@@ -32,12 +32,12 @@ __device__ __forceinline__ bf16x8 ld_cached(const bf16_t* p) { return *reinterpr
 // contiguous, a wave's loads are whole cache lines back to back (measured +8..30 % over 64-byte pieces of 16 separate rows).
 template <int MT, int NT, int EPI, bool PRE>
 __global__ void __launch_bounds__(kSkWaves * 64) gemm_skinny_kernel(const bf16_t* __restrict__ x, int64_t lda, const bf16_t* __restrict__ W,
-                                                                   int64_t ldw, void* __restrict__ out, int64_t ldc, int M, int N, int K) {
+                                                                   int64_t ldw, void* __restrict__ out, int64_t ldc, int M, int N, int K, SkinnyRope ra) {
     __shared__ float red[kSkWaves][NT][MT][64][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     // rows of W this block owns
     int row0[NT];
-    if constexpr (EPI == SK_SWIGLU) {
+    if constexpr (EPI == SK_SWIGLU || EPI == SK_QKV_ROPE) {     // (first group, partner group) of a 64-row block
         const int j = blockIdx.x >> 1, q = blockIdx.x & 1;          // 64-row block j of gu_w: gate rows 64 j + 16 q, up rows + 32
         row0[0] = 64 * j + 16 * q;
         row0[1] = row0[0] + 32;
@@ -99,13 +99,14 @@ __global__ void __launch_bounds__(kSkWaves * 64) gemm_skinny_kernel(const bf16_t
     if constexpr (U >= 8) { if (s + 4 <= s1) batch(std::integral_constant<int, 4>{}); }
     if (s + 2 <= s1) batch(std::integral_constant<int, 2>{});
     if (s < s1) batch(std::integral_constant<int, 1>{});
+
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[w][i][j][lane][0]) = acc[i][j];
     __syncthreads();
     // the eight partial tiles in wave order; thread -> (n-tile i, m-tile j, lane slot): D[feature 4 g + r][row r16]
-    constexpr int kOutTiles = EPI == SK_SWIGLU ? 1 : NT;
+    constexpr int kOutTiles = (EPI == SK_SWIGLU || EPI == SK_QKV_ROPE) ? 1 : NT;
     for (int e = threadIdx.x; e < kOutTiles * MT * 64; e += kSkWaves * 64) {
         const int i = e / (MT * 64), j = (e / 64) % MT, l = e & 63;
         const int m = j * 16 + (l & 15), gg = l >> 4;
@@ -113,7 +114,45 @@ __global__ void __launch_bounds__(kSkWaves * 64) gemm_skinny_kernel(const bf16_t
 #pragma unroll
         for (int ww = 1; ww < kSkWaves; ++ww) v += *reinterpret_cast<const f32x4*>(&red[ww][i][j][l][0]);
         if (m >= M) continue;
-        if constexpr (EPI == SK_SWIGLU) {
+        if constexpr (EPI == SK_QKV_ROPE) {
+            // the QKV + RoPE epilogue of the towers for ONE new token per row (epilogue.h EpiQkvRope; head_dim 64: a 64-row block is a
+            // head, partner = channel + 32; head_dim 128: packed rows, block 2 h holds channels (j, j + 64) for j < 32, block 2 h + 1
+            // those for 32 <= j < 64): query * q_scale, rotation at position prompt_len + step, then q -> qbuf, k -> the generated
+            // key segment at index step, v -> the transposed value segment
+            f32x4 u = *reinterpret_cast<const f32x4*>(&red[0][1][j][l][0]);
+#pragma unroll
+            for (int ww = 1; ww < kSkWaves; ++ww) u += *reinterpret_cast<const f32x4*>(&red[ww][1][j][l][0]);
+            const int n = row0[0] + 4 * gg;
+            if (n < N) {
+                const int hd = ra.d, half = hd >> 1, blk = n >> 6;
+                const int head = hd == 64 ? blk : blk >> 1;
+                const int ch = (hd == 64 ? 0 : 32 * (blk & 1)) + (n & 31);
+                const int step = min(max(ra.step[0], 0), ra.G - 1);
+                if (head < ra.nh + ra.nkv) {
+                    const bool is_q = head < ra.nh;
+                    const float qs = is_q ? ra.q_scale : 1.0f, pos = (float)(ra.prompt_len[m / ra.group] + step);
+                    float o1[4], o2[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float a = __fmul_rn(pos, ra.inv_freq[ch + t]);
+                        const float c = cosf(a), sn = sinf(a), a1 = v[t] * qs, a2 = u[t] * qs;
+                        o1[t] = a1 * c - a2 * sn;
+                        o2[t] = a2 * c + a1 * sn;
+                    }
+                    bf16_t* dst = is_q ? (bf16_t*)ra.q + ((int64_t)m * ra.nh + head) * hd
+                                       : (bf16_t*)ra.k + (((int64_t)m * ra.nkv + (head - ra.nh)) * ra.G + step) * hd;
+                    store4(dst + ch, o1);
+                    store4(dst + ch + half, o2);
+                } else {
+                    bf16_t* dst = (bf16_t*)ra.vt + ((int64_t)m * ra.nkv + (head - ra.nh - ra.nkv)) * hd * ra.G + step;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dst[(int64_t)(ch + t) * ra.G] = from_f32<bf16_t>(v[t]);
+                        dst[(int64_t)(ch + t + half) * ra.G] = from_f32<bf16_t>(u[t]);
+                    }
+                }
+            }
+        } else if constexpr (EPI == SK_SWIGLU) {
             f32x4 u = *reinterpret_cast<const f32x4*>(&red[0][1][j][l][0]);
 #pragma unroll
             for (int ww = 1; ww < kSkWaves; ++ww) u += *reinterpret_cast<const f32x4*>(&red[ww][1][j][l][0]);
@@ -149,29 +188,30 @@ __global__ void __launch_bounds__(kSkWaves * 64) gemm_skinny_kernel(const bf16_t
 }
 
 template <int MT, int EPI, bool PRE>
-int launch_mt(const bf16_t* x, int64_t lda, const bf16_t* W, int64_t ldw, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
-    if constexpr (EPI == SK_SWIGLU) {
-        gemm_skinny_kernel<MT, 2, EPI, PRE><<<(unsigned)(N / 32), kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K);
+int launch_mt(const bf16_t* x, int64_t lda, const bf16_t* W, int64_t ldw, void* out, int64_t ldc, int M, int N, int K, const SkinnyRope& ra, hipStream_t s) {
+    if constexpr (EPI == SK_SWIGLU || EPI == SK_QKV_ROPE) {
+        gemm_skinny_kernel<MT, 2, EPI, PRE><<<(unsigned)(N / 32), kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K, ra);
     } else {
         // feature tiles per block: more of them re-use the x fragments of a step, fewer give the small projections enough blocks
         const int tiles = (N + 15) / 16;
-        if (MT <= 2 && tiles >= 4096) gemm_skinny_kernel<MT, 4, EPI, PRE><<<(unsigned)((tiles + 3) / 4), kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K);
-        else if (tiles >= 1024) gemm_skinny_kernel<MT, 2, EPI, PRE><<<(unsigned)((tiles + 1) / 2), kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K);
-        else gemm_skinny_kernel<MT, 1, EPI, PRE><<<(unsigned)tiles, kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K);
+        if (MT <= 2 && tiles >= 4096) gemm_skinny_kernel<MT, 4, EPI, PRE><<<(unsigned)((tiles + 3) / 4), kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K, ra);
+        else if (tiles >= 1024) gemm_skinny_kernel<MT, 2, EPI, PRE><<<(unsigned)((tiles + 1) / 2), kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K, ra);
+        else gemm_skinny_kernel<MT, 1, EPI, PRE><<<(unsigned)tiles, kSkWaves * 64, 0, s>>>(x, lda, W, ldw, out, ldc, M, N, K, ra);
     }
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }
 
 template <int EPI, bool PRE>
-int launch_pre(const bf16_t* x, int64_t lda, const bf16_t* W, int64_t ldw, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
-    if (M <= 16) return launch_mt<1, EPI, PRE>(x, lda, W, ldw, out, ldc, M, N, K, s);
-    if (M <= 32) return launch_mt<2, EPI, PRE>(x, lda, W, ldw, out, ldc, M, N, K, s);
-    return launch_mt<4, EPI, PRE>(x, lda, W, ldw, out, ldc, M, N, K, s);
+int launch_pre(const bf16_t* x, int64_t lda, const bf16_t* W, int64_t ldw, void* out, int64_t ldc, int M, int N, int K, const SkinnyRope& ra, hipStream_t s) {
+    if (M <= 16) return launch_mt<1, EPI, PRE>(x, lda, W, ldw, out, ldc, M, N, K, ra, s);
+    if (M <= 32) return launch_mt<2, EPI, PRE>(x, lda, W, ldw, out, ldc, M, N, K, ra, s);
+    return launch_mt<4, EPI, PRE>(x, lda, W, ldw, out, ldc, M, N, K, ra, s);
 }
 template <int EPI>
-int launch_epi(const bf16_t* x, int64_t lda, const bf16_t* W, int64_t ldw, void* out, int64_t ldc, int M, int N, int K, int pre, hipStream_t s) {
-    return pre ? launch_pre<EPI, true>(x, lda, W, ldw, out, ldc, M, N, K, s) : launch_pre<EPI, false>(x, lda, W, ldw, out, ldc, M, N, K, s);
+int launch_epi(const bf16_t* x, int64_t lda, const bf16_t* W, int64_t ldw, void* out, int64_t ldc, int M, int N, int K, int pre, hipStream_t s,
+               const SkinnyRope& ra = SkinnyRope{}) {
+    return pre ? launch_pre<EPI, true>(x, lda, W, ldw, out, ldc, M, N, K, ra, s) : launch_pre<EPI, false>(x, lda, W, ldw, out, ldc, M, N, K, ra, s);
 }
 
 // out[((tile * steps + step) * 64 + lane) * 8 + e] = W[16 tile + lane % 16][32 step + 8 (lane / 16) + e], rows >= N as zeros
@@ -216,6 +256,16 @@ int launch_gemm_skinny(const void* x, int64_t lda, const void* W, int64_t ldw, v
     return P2T_ERR_UNSUPPORTED;
 }
 
+
+// The QKV projection of ONE new token per row with the rotation and the cache append as its epilogue (head_dim 64 / 128, no q/k
+// norm: the shapes whose prefill runs the fused QKV + RoPE epilogue).  N = (nh + 2 nkv) * head_dim rows of qkv_w.
+int launch_gemm_skinny_qkv_rope(const void* x, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K, const SkinnyRope& ra,
+                                hipStream_t s, int pre) {
+    if (M < 1 || M > 64 || N % 64 || K < 32 || K % 32 || lda % 8 || lda < K || (!pre && (ldw % 8 || ldw < K)) || (ra.d != 64 && ra.d != 128) ||
+        N != (int64_t)(ra.nh + 2 * ra.nkv) * ra.d)
+        return P2T_ERR_UNSUPPORTED;
+    return launch_epi<SK_QKV_ROPE>((const bf16_t*)x, lda, (const bf16_t*)W, ldw, nullptr, 0, (int)M, (int)N, (int)K, pre, s, ra);
+}
 
 int launch_preshuffle(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s) {
     P2T_REQUIRE(W && out && N > 0 && N < (1 << 30) && K >= 32 && K % 32 == 0 && ldw >= K && ldw % 8 == 0, "p2t_preshuffle_w: bad arguments (K %% 32, ldw %% 8)");

@@ -14,6 +14,8 @@ int launch_layernorm(const float* x, int64_t ld_x, const float* w, const float* 
                      int64_t rows, int64_t cols, int out_dtype, hipStream_t s);
 int launch_rmsnorm(const float* x, int64_t ld_x, const float* w, float eps, void* y, int64_t ld_y, int64_t rows,
                    int64_t cols, int out_dtype, hipStream_t s);
+int launch_rmsnorm_few_rows(const float* x, int64_t ld_x, const float* w, float eps, void* y, int64_t ld_y, int64_t rows, int64_t cols,
+                            int out_dtype, hipStream_t s);     // decode step: block per row (norm.hip)
 int launch_l2norm(const void* x, int in_dtype, int64_t ld_x, void* y, int out_dtype, int64_t ld_y, float* inv_norm,
                   int64_t rows, int64_t cols, float eps, hipStream_t s);
 
@@ -69,6 +71,16 @@ struct GemmArgs {
 int gemm_nt(const GemmArgs& a, hipStream_t s);
 // weight-streaming GEMM for M <= 64 rows (gemm_skinny.hip): bf16, epilogues STORE / STORE_F32 / RESID / SWIGLU, no bias;
 // P2T_ERR_UNSUPPORTED for anything else
+// epilogue arguments of launch_gemm_skinny_qkv_rope: rotation at position prompt_len[row / group] + step[0] and the cache append
+struct SkinnyRope {
+    const float* inv_freq = nullptr; const int32_t* prompt_len = nullptr; const int32_t* step = nullptr;
+    int group = 1, nh = 0, nkv = 0, d = 0, G = 0; float q_scale = 1.f;
+    void* q = nullptr;       // bf16 [M, nh, d]
+    void* k = nullptr;       // bf16 [M, nkv, G, d]   (one layer of p2t_kv_cache.k_gen)
+    void* vt = nullptr;      // bf16 [M, nkv, d, G]   (one layer of p2t_kv_cache.vt_gen)
+};
+int launch_gemm_skinny_qkv_rope(const void* x, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K, const SkinnyRope& ra,
+                                hipStream_t s, int pre);
 // pre: W is the pre-shuffled stream copy written by launch_preshuffle (ldw unused)
 int launch_gemm_skinny(const void* x, int64_t lda, const void* W, int64_t ldw, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype,
                        int out_dtype, int epilogue, hipStream_t s, int pre = 0);

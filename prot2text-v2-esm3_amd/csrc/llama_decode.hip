@@ -16,8 +16,12 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <atomic>
+
 namespace p2t {
 namespace {
+
+std::atomic<int> g_decode_fusion{1};        // p2t_set_decode_fusion (tests): 0 = projection and rotation + append as two launches
 
 // ---------------------------------------------------------------------------------------------
 // compaction of the prompt rows
@@ -670,36 +674,48 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
         const p2t_llama_layer& L = w->layers[l];
         P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_decode_step: q_norm_w and k_norm_w go together (layer %d)", l);
         const int fused_prefill = !L.q_norm_w && (d == 64 || d == 128);
-        P2T_TRY(launch_rmsnorm(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
-        GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, P2T_F32, P2T_EPI_STORE_F32, 0, -1, (int)NQKV, 0.f, 0, 0};
-        P2T_TRY(gemm_nt(g1, s, stream_w ? ws_layers[l].qkv_w : nullptr));
-        {
-            const unsigned grid = (unsigned)ceil_div((int64_t)BB * (nh + 2 * nkv), 4);
+        P2T_TRY(launch_rmsnorm_few_rows(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
+        bool roped = false;
+        if (fused_prefill && dt == P2T_BF16 && g_decode_fusion.load()) {   // projection + rotation + cache append in one launch (SK_QKV_ROPE)
             const size_t per_g = (size_t)BB * nkv * cache->G * dp;
-            if (dt == P2T_BF16)
-                rope_append_kernel<bf16_t><<<grid, 256, 0, s>>>(b.qkv, NQKV, inv_freq, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, cache->prompt_len,
-                                                                cache->step, cache->group, (bf16_t*)b.qb, (bf16_t*)cache->k_gen + per_g * l,
-                                                                (bf16_t*)cache->vt_gen + per_g * l, BB, nh, nkv, d, dp, cache->G, q_fold,
-                                                                d == 128 && !L.q_norm_w, !fused_prefill);
-            else
-                rope_append_kernel<float><<<grid, 256, 0, s>>>(b.qkv, NQKV, inv_freq, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, cache->prompt_len,
-                                                               cache->step, cache->group, (float*)b.qb, (float*)cache->k_gen + per_g * l,
-                                                               (float*)cache->vt_gen + per_g * l, BB, nh, nkv, d, dp, cache->G, q_fold,
-                                                               d == 128 && !L.q_norm_w, 0);
-            P2T_LAUNCH_CHECK();
+            SkinnyRope ra;
+            ra.inv_freq = inv_freq; ra.prompt_len = cache->prompt_len; ra.step = cache->step; ra.group = cache->group;
+            ra.nh = nh; ra.nkv = nkv; ra.d = d; ra.G = cache->G; ra.q_scale = q_fold;
+            ra.q = b.qb; ra.k = (bf16_t*)cache->k_gen + per_g * l; ra.vt = (bf16_t*)cache->vt_gen + per_g * l;
+            const int r = launch_gemm_skinny_qkv_rope(b.h, Hp, stream_w ? ws_layers[l].qkv_w : L.qkv_w, Hp, M, NQKV, Hp, ra, s, stream_w);
+            if (r != P2T_ERR_UNSUPPORTED) { P2T_TRY(r); roped = true; }
+        }
+        if (!roped) {
+            GemmArgs g1{b.h, Hp, L.qkv_w, Hp, nullptr, b.qkv, NQKV, nullptr, M, NQKV, Hp, dt, P2T_F32, P2T_EPI_STORE_F32, 0, -1, (int)NQKV, 0.f, 0, 0};
+            P2T_TRY(gemm_nt(g1, s, stream_w ? ws_layers[l].qkv_w : nullptr));
+            {
+                const unsigned grid = (unsigned)ceil_div((int64_t)BB * (nh + 2 * nkv), 4);
+                const size_t per_g = (size_t)BB * nkv * cache->G * dp;
+                if (dt == P2T_BF16)
+                    rope_append_kernel<bf16_t><<<grid, 256, 0, s>>>(b.qkv, NQKV, inv_freq, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, cache->prompt_len,
+                                                                    cache->step, cache->group, (bf16_t*)b.qb, (bf16_t*)cache->k_gen + per_g * l,
+                                                                    (bf16_t*)cache->vt_gen + per_g * l, BB, nh, nkv, d, dp, cache->G, q_fold,
+                                                                    d == 128 && !L.q_norm_w, !fused_prefill);
+                else
+                    rope_append_kernel<float><<<grid, 256, 0, s>>>(b.qkv, NQKV, inv_freq, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, cache->prompt_len,
+                                                                   cache->step, cache->group, (float*)b.qb, (float*)cache->k_gen + per_g * l,
+                                                                   (float*)cache->vt_gen + per_g * l, BB, nh, nkv, d, dp, cache->G, q_fold,
+                                                                   d == 128 && !L.q_norm_w, 0);
+                P2T_LAUNCH_CHECK();
+            }
         }
         if (dt == P2T_BF16) P2T_TRY(launch_attn_decode_t<bf16_t>(b, cache, l, BB, nh, nkv, d, dp, c_exp, 1, QO, s));
         else P2T_TRY(launch_attn_decode_t<float>(b, cache, l, BB, nh, nkv, d, dp, c_exp, 0, QO, s));
         GemmArgs g2{b.ao, QO, L.o_w, QO, nullptr, b.x, H, nullptr, M, H, QO, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g2, s, stream_w ? ws_layers[l].o_w : nullptr));
-        P2T_TRY(launch_rmsnorm(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
+        P2T_TRY(launch_rmsnorm_few_rows(b.x, H, L.ln2_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
         GemmArgs g3{b.h, Hp, L.gu_w, Hp, nullptr, b.act, Fp, nullptr, M, 2 * F, Hp, dt, dt, P2T_EPI_SWIGLU, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g3, s, stream_w ? ws_layers[l].gu_w : nullptr));
         GemmArgs g4{b.act, Fp, L.down_w, Fp, nullptr, b.x, H, nullptr, M, H, Fp, dt, P2T_F32, P2T_EPI_RESID, 0, -1, -1, 0.f, 0, 0};
         P2T_TRY(gemm_nt(g4, s, stream_w ? ws_layers[l].down_w : nullptr));
     }
-    P2T_TRY(launch_rmsnorm(b.x, H, w->final_norm_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
     P2T_REQUIRE(!lm_head_preshuffled || dt == P2T_BF16, "p2t_llama_decode_step: pre-shuffled weights are a bf16 layout");
+    P2T_TRY(launch_rmsnorm_few_rows(b.x, H, w->final_norm_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
     GemmArgs gh{b.h, Hp, lm_head, ld_head, nullptr, logits, ld_logits, nullptr, M, c->vocab, Hp, dt, dt, P2T_EPI_STORE, 0, -1, -1, 0.f, 0, 0};
     P2T_TRY(gemm_nt(gh, s, lm_head_preshuffled ? lm_head : nullptr));
     advance_kernel<<<1, 1, 0, s>>>(cache->step);
@@ -762,4 +778,9 @@ extern "C" int p2t_attention_decode(const void* q, const void* k_prompt, const v
     if (dtype == P2T_BF16) return launch_attn_decode_t<bf16_t>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 1, ld_out, s, use_mfma != 0);
     P2T_REQUIRE(use_mfma <= 0, "p2t_attention_decode: the matrix-pipe kernel is bf16 only");
     return launch_attn_decode_t<float>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 0, ld_out, s);
+}
+
+extern "C" int p2t_set_decode_fusion(int on) {
+    g_decode_fusion.store(on != 0);
+    return P2T_OK;
 }

@@ -98,6 +98,52 @@ static int launch_norm_t(const float* x, int64_t ld_x, const float* w, const flo
     return P2T_ERR_UNSUPPORTED;
 }
 
+// A handful of rows (one decode step: rows = sequences that generate): one BLOCK per row, the row's and the weight's 16-byte pieces
+// all requested before anything is waited for -- one round trip to memory instead of the wave-per-row kernel's two (9.2 -> 4 us
+// for 8 x 4096, 65 of them per generated token).  Same arithmetic as norm_kernel<.., RMS> except for the order of the sum.
+template <int NV, typename Tout>
+__global__ void __launch_bounds__(256) rmsnorm_rows_kernel(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ w, float eps,
+                                                           Tout* __restrict__ y, int64_t ld_y, int cols) {
+    __shared__ float red[4];
+    const float* xr = x + (int64_t)blockIdx.x * ld_x;
+    float v[NV][4], wv[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c < cols) { load4(xr + c, v[i]); load4(w + c, wv[i]); }
+        else { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; wv[i][0] = wv[i][1] = wv[i][2] = wv[i][3] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    const float rstd = rsqrtf(block_sum<4>(s, red) / (float)cols + eps);
+    Tout* yr = y + (int64_t)blockIdx.x * ld_y;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c < ld_y) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = c < cols ? wv[i][j] * (v[i][j] * rstd) : 0.f;
+            store4(yr + c, o);
+        }
+    }
+}
+
+template <typename Tout>
+static int launch_rmsnorm_rows(const float* x, int64_t ld_x, const float* w, float eps, Tout* y, int64_t ld_y, int64_t rows, int64_t cols, hipStream_t s) {
+    const int64_t span = ld_y > cols ? ld_y : cols;
+#define P2T_RROWS_CASE(NV)                                                                                            \
+    if (span <= (NV) * 1024) {                                                                                        \
+        rmsnorm_rows_kernel<NV, Tout><<<(unsigned)rows, 256, 0, s>>>(x, ld_x, w, eps, y, ld_y, (int)cols);            \
+        P2T_LAUNCH_CHECK();                                                                                           \
+        return P2T_OK;                                                                                                \
+    }
+    P2T_RROWS_CASE(1) P2T_RROWS_CASE(2) P2T_RROWS_CASE(4) P2T_RROWS_CASE(8)
+#undef P2T_RROWS_CASE
+    return P2T_ERR_UNSUPPORTED;
+}
+
 int launch_layernorm(const float* x, int64_t ld_x, const float* w, const float* b, float eps, void* y, int64_t ld_y,
                      int64_t rows, int64_t cols, int out_dtype, hipStream_t s) {
     if (rows == 0) return P2T_OK;
@@ -109,6 +155,15 @@ int launch_rmsnorm(const float* x, int64_t ld_x, const float* w, float eps, void
     if (rows == 0) return P2T_OK;
     if (out_dtype == P2T_BF16) return launch_norm_t<bf16_t, true>(x, ld_x, w, nullptr, eps, (bf16_t*)y, ld_y, rows, cols, s);
     return launch_norm_t<float, true>(x, ld_x, w, nullptr, eps, (float*)y, ld_y, rows, cols, s);
+}
+
+// the decode step's RMSNorm (a few rows): block per row, one round trip; falls back to the wave-per-row kernel beyond 8192 columns
+int launch_rmsnorm_few_rows(const float* x, int64_t ld_x, const float* w, float eps, void* y, int64_t ld_y, int64_t rows, int64_t cols, int out_dtype,
+                            hipStream_t s) {
+    if (rows == 0) return P2T_OK;
+    int r = out_dtype == P2T_BF16 ? launch_rmsnorm_rows<bf16_t>(x, ld_x, w, eps, (bf16_t*)y, ld_y, rows, cols, s)
+                                  : launch_rmsnorm_rows<float>(x, ld_x, w, eps, (float*)y, ld_y, rows, cols, s);
+    return r == P2T_ERR_UNSUPPORTED ? launch_rmsnorm(x, ld_x, w, eps, y, ld_y, rows, cols, out_dtype, s) : r;
 }
 
 // ---------------------------------------------------------------------------------------------
