@@ -39,7 +39,8 @@ def kernel_src_sha16():
 
 
 FAMILIES = {"gemm_nt_mfma": "gemm_nt_mfma*", "gemm_nt_w4": "gemm_nt_mfma*",     # one family: the bf16 MFMA GEMM in its eight- and four-wave forms
-            "gemm_nt_fp8": "gemm_nt_fp8*", "attn_mfma_kernel": "attn_mfma_kernel", "norm_kernel": "norm_kernel"}
+            "gemm_nt_fp8": "gemm_nt_fp8*", "attn_mfma_kernel": "attn_mfma_kernel", "norm_kernel": "norm_kernel",
+            "gemm_skinny_kernel": "gemm_skinny_kernel", "attn_decode_mfma_kernel": "attn_decode_mfma_kernel"}   # the decode step (generate)
 
 
 def family(name):
