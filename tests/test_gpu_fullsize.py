@@ -293,3 +293,42 @@ def test_cfg3_ragged_batch_trimmed_segments_equal_padded_step(cfg3):
     observe("cfg3.ragged_trim_vs_padded.loss", abs(l1 - l0) / max(1.0, abs(l0)), 2e-2, "abs/max(1,|ref|)")
     observe("cfg3.ragged_trim_vs_padded.grads", rel(g1, g0), 6e-2)
     torch.cuda.empty_cache()
+
+
+def test_cfg3_generate_cached_steps_equal_the_cacheless_forward(cfg3):
+    """`generate` at full model size (ESM2-3B -> adapter -> placeholder scatter -> all 32 layers of Llama-3.1-8B): the ids come back
+    as the reference returns them, and the logits of every cached decode step equal the model's own cache-LESS forward over the
+    compacted prompt + the generated ids -- the size-independent property that pins the KV-cache path (prefill cache write, stream
+    copies of the weights, fused rotation + append, single-query attention, graph replay) where the CPU oracle cannot go; the forward
+    it is compared with is pinned on the oracle by the tests above and tests/test_gpu_sft_forward.py."""
+    model, Tp = cfg3["model"], cfg3["Tp"]
+    model.set_gemm_dtype("model")
+    B, n_prompt, n_new = 3, 24, 6
+    lens = [Tp, 411, 37]
+    pid, pmask = synth.protein_batch(91, B, Tp, lens)
+    ph = model.config.placeholder_id
+    rs = np.random.RandomState(5)
+    T = Tp + n_prompt
+    ids = np.full((B, T), 128002, dtype=np.int64)
+    mask = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lens):                       # left padded, as the reference's collater builds its prompts
+        row = np.concatenate([rs.randint(0, 128000, 8), np.full(n, ph), rs.randint(0, 128000, n_prompt - 8)])
+        ids[b, T - len(row):] = row
+        mask[b, T - len(row):] = 1
+    kw = dict(inputs=to_dev(ids), attention_mask=to_dev(mask), protein_input_ids=to_dev(pid), protein_attention_mask=to_dev(pmask))
+    out = model.generate(**kw, max_new_tokens=n_new, eos_token_id=None, pad_token_id=128002, do_sample=False, return_dict_in_generate=True,
+                         output_logits=True)
+    toks, lg = to_np(out.sequences), to_np(torch.stack(out.logits, 0))
+    assert toks.shape == (B, n_new) and np.isfinite(lg).all()
+    eager = model.generate(**kw, max_new_tokens=n_new, eos_token_id=None, pad_token_id=128002, do_sample=False, use_graph=False, stream_copy=False)
+    assert np.array_equal(to_np(eager), toks)           # graph replay + stream copies == eager launches on the row-major weights
+    emb, m2 = model(input_ids=kw["inputs"], attention_mask=kw["attention_mask"], protein_input_ids=kw["protein_input_ids"],
+                    protein_attention_mask=kw["protein_attention_mask"], return_decoder_inputs=True)
+    dec = model.llama_decoder
+    for b in range(B):
+        valid = torch.from_numpy(mask[b] != 0).to(emb.device)
+        row = torch.cat([emb[b][valid], dec.model.embed(to_dev(toks[b:b + 1, :-1]))[0]], 0)[None]
+        full = to_np(dec(inputs_embeds=row).logits.float())[0]
+        n0 = int(mask[b].sum())
+        observe(f"cfg3.generate_cache_vs_full_forward.row{b}", rel(lg[:, b], full[n0 - 1:n0 - 1 + n_new]), 3e-2)
+    torch.cuda.empty_cache()
