@@ -63,6 +63,8 @@ def parse():
                          "(ContrastiveTrainer(overlap_streams=True): co-scheduled kernels fill each other's partial rounds, +2-3 %%); the "
                          "roofline block's per-kernel event times always come from a separate single-stream pass after the timed region")
     ap.add_argument("--overlap", action="store_true", help="(default since round 3; accepted for old command lines)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not enqueue the next step's frozen towers beside this step's backward / optimizer tail (the timed default does)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="pairs of the benchmarked config in the CPU-baseline sample")
     ap.add_argument("--cpu-cfg2", action="store_true", help="also time config 2 on the CPU (1 warm-up + 1 repetition, ~1.5 min)")
     ap.add_argument("--no-batch64-check", action="store_true",
@@ -335,8 +337,13 @@ def main():
         trainer.step(batch)
     barrier()
     t0 = time.perf_counter()
+    # Steps are pipelined through the frozen towers (ContrastiveTrainer.step(batch, next_batch)): the encoder / text tower of step
+    # i + 1 depend on nothing step i's optimizer writes, so they are enqueued on the side streams beside step i's backward + clip +
+    # AdamW tail.  The timed region starts and ends clean: the warm-up's last step prefetches nothing and neither does the last timed
+    # step, so exactly `steps` tower passes and `steps` tails run between the two barriers.
+    pipeline = overlap and not args.no_pipeline
     for i in range(args.steps):
-        loss = trainer.step(batch)
+        loss = trainer.step(batch, next_batch=batch if (pipeline and i + 1 < args.steps) else None)
     barrier()
     elapsed = time.perf_counter() - t0
     loss = trainer.global_loss(loss)            # mean over ranks (a copy; outside the timed region)
@@ -474,6 +481,8 @@ def main():
                                              "segments_rows_x_length": [[b - a, t] for a, b, t, _ in t_trim._segments(srt, 64, Tmax)]}
             del t_trim
         out["config"]["streams"] = ("text tower and encoder segments on separate HIP streams" if overlap else "one HIP stream")
+        out["config"]["pipeline"] = ("frozen towers of step i + 1 enqueued beside the backward / optimizer tail of step i (steps - 1 of the timed steps; "
+                                     "the region starts and ends with nothing in flight)" if pipeline else "none")
         if one_stream_rate is not None:
             # the same step on ONE stream, taken from the event pass above (includes the ~1.5 % cost of the event records)
             out["config"]["one_stream_check"] = {"samples_per_s": round(one_stream_rate, 2)}

@@ -327,6 +327,7 @@ class ContrastiveTrainer:
         # towers / segments on separate HIP streams: default on for ragged segments (short segments leave CUs idle: +8 %
         # measured), off otherwise (+2.4 %, but per-kernel timings then include the co-runner -- bench.py measures without)
         self.overlap_streams, self._streams = (trim_padding if overlap_streams is None else bool(overlap_streams)), {}
+        self._pf, self._next = None, None            # towers of the next batch already in flight (prefetch_towers) / the batch step() announced
         if gradient_accumulation_steps < 1:
             raise ValueError("gradient_accumulation_steps must be >= 1")
         self.gradient_accumulation_steps, self._micro = int(gradient_accumulation_steps), 0
@@ -448,19 +449,14 @@ class ContrastiveTrainer:
         # is filled by another stream's blocks instead of idling CUs.  Everything joins on the caller's stream.
         main = torch.cuda.current_stream()
         encs, pre = {}, {}
-        if self.overlap_streams:
-            start = main.record_event()
-            with torch.cuda.stream(self._stream(0)):
-                torch.cuda.current_stream().wait_event(start)
-                pre["text"] = self.text_embeddings(tid, tmask, batch)
-                pre["text"].record_stream(main)
-                pre["ev"] = torch.cuda.current_stream().record_event()
-            for s, (r0, r1, Ts, _) in enumerate(segs):
-                with torch.cuda.stream(self._stream(1 + s % 2)):
-                    torch.cuda.current_stream().wait_event(start)
-                    enc = m.esm_encoder.encode(pid[r0:r1, :Ts], pmask[r0:r1, :Ts])
-                    enc.record_stream(main)
-                    encs[s] = (enc, torch.cuda.current_stream().record_event())
+        pf, self._pf = self._pf, None
+        if pf is not None and pf["batch"] is batch and pf["segs"] == segs:
+            encs, pre = pf["encs"], pf["pre"]          # the frozen towers of THIS batch were enqueued during the previous step's tail
+        elif self.overlap_streams:
+            encs, pre = self._launch_towers(batch, segs, main.record_event())
+        if self._next is not None and backward:
+            # (the side streams run it behind this batch's towers: it meets the backward / optimizer tail on the caller's stream)
+            self.prefetch_towers(self._next)
 
         def text_fn():
             if pre:
@@ -536,6 +532,47 @@ class ContrastiveTrainer:
                                           prefetch_fn=prefetch_fn if (cw == 0.0 and self.global_negatives and sharding.world_info(self.group)[1] > 1) else None)
         return self.loss
 
+    def _launch_towers(self, batch, segs, start):
+        """Text tower on side stream 0, the encoder of segment s on side stream 1 + s % 2; `start`: an event of the caller's stream
+        the side streams wait for (None: nothing of the caller's stream feeds them -- `prefetch_towers`)."""
+        m, main = self.model, torch.cuda.current_stream()
+        pid, pmask = batch["protein_input_ids"], batch["protein_attention_mask"]
+        tid, tmask = batch["description_input_ids"], batch["description_attention_mask"]
+        encs, pre = {}, {}
+        with torch.cuda.stream(self._stream(0)):
+            if start is not None:
+                torch.cuda.current_stream().wait_event(start)
+            pre["text"] = self.text_embeddings(tid, tmask, batch)
+            pre["text"].record_stream(main)
+            pre["ev"] = torch.cuda.current_stream().record_event()
+        for s, (r0, r1, Ts, _) in enumerate(segs):
+            with torch.cuda.stream(self._stream(1 + s % 2)):
+                if start is not None:
+                    torch.cuda.current_stream().wait_event(start)
+                enc = m.esm_encoder.encode(pid[r0:r1, :Ts], pmask[r0:r1, :Ts])
+                enc.record_stream(main)
+                encs[s] = (enc, torch.cuda.current_stream().record_event())
+        return encs, pre
+
+    def prefetch_towers(self, next_batch: Dict[str, torch.Tensor], ready: Optional["torch.cuda.Event"] = None):
+        """Enqueue the FROZEN towers of the next batch now, on the side streams: neither the ESM2 encoder nor the text tower depends
+        on the optimizer step that is still running on the caller's stream, so the tail of this step (adapter backward, readout,
+        loss, clip + AdamW: small grids and HBM-bound passes that leave most CUs idle -- and, across ranks, the gradient
+        all-reduce) overlaps with the next step's first GEMMs.  The next `step(next_batch)` (the same dict object) picks the
+        results up; any other batch discards them.  `ready`: an event after which next_batch's tensors are valid (e.g. the copy
+        stream's event of a DevicePrefetcher); None = they already are.  A no-op without overlap_streams."""
+        if not self.overlap_streams or next_batch is None:
+            return
+        B, T = next_batch["protein_input_ids"].shape
+        segs = self._segments(next_batch, B, T)
+        self.model.esm_encoder.ensure_engine()
+        self.model.llama_decoder.model.ensure_engine(self.layer)
+        if ready is not None:
+            for i in range(3):
+                self._stream(i).wait_event(ready)
+        encs, pre = self._launch_towers(next_batch, segs, None)
+        self._pf = dict(batch=next_batch, segs=segs, encs=encs, pre=pre)
+
     def global_loss(self, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Mean over ranks of `loss` (default: the last step's) = the loss of the global batch; one tiny all-reduce, no host
         sync.  `step()` itself returns the rank-local loss, as the reference's teacher_forcing_forward_pass does -- the
@@ -589,11 +626,15 @@ class ContrastiveTrainer:
         if self.schedule is not None and self.schedule_step == "epoch":
             self.schedule.step()
 
-    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def step(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         """One micro-batch of `train_epoch` (train_contrast.py:417-465): gradients of loss / GA are accumulated, and every
-        `gradient_accumulation_steps` calls clip + AdamW run.  Returns this batch's (unscaled) loss."""
+        `gradient_accumulation_steps` calls clip + AdamW run.  Returns this batch's (unscaled) loss.
+        next_batch (optional, already on the device): its frozen towers are enqueued on the side streams as soon as this step's
+        forward has consumed the current ones, i.e. they run beside this step's backward / optimizer tail (`prefetch_towers`)."""
         accumulate, grad_scale, reduce, do_step = sharding.micro_step_plan(self._micro, self.gradient_accumulation_steps)
+        self._next = next_batch
         loss = self.forward_backward(batch, accumulate=accumulate, grad_scale=grad_scale, reduce=reduce)
+        self._next = None
         self._micro += 1
         if do_step:
             self.optimizer_step()

@@ -208,3 +208,28 @@ def test_two_ranks_epoch_on_one_gpu_equals_the_single_process_epoch(tmp_path):
     assert one["batches"] == 3.0 and one["aborted"]
     assert sum(l.startswith("[epoch=1/1, train_loss=") for l in two[0]["lines"]) == 2 and not any(l.startswith("[epoch") for l in two[1]["lines"])
     assert any(l.startswith("Impossible batch_loss") for l in two[1]["lines"]) and not any(l.startswith("Impossible") for l in two[0]["lines"])
+
+
+def test_steps_pipelined_through_the_frozen_towers_equal_the_plain_sequence():
+    """`step(batch, next_batch)`: the encoder / text tower of the next batch are enqueued on the side streams beside this step's
+    backward + AdamW tail (they depend on nothing the optimizer writes).  Same kernels, same inputs: the losses and the parameters
+    after four steps equal the plain sequence bit for bit -- also when the announced batch is NOT the one that follows (the
+    prefetched towers are dropped), with gradient accumulation, and with the towers' default stream layout off (a no-op)."""
+    to_cuda = lambda b: {k: v.to(dev()) for k, v in b.items()}
+    batches = [to_cuda(b) for b in _host_batches(4)]
+    ref = _trainer(overlap_streams=True)
+    want = [float(to_np(ref.step(b))[0]) for b in batches]
+    want_p = to_np(ref.flat_p).copy()
+    for ga, kw in ((1, dict(overlap_streams=True)), (2, dict(overlap_streams=True)), (1, dict(overlap_streams=False))):
+        plain, piped = _trainer(ga=ga, **kw), _trainer(ga=ga, **kw)
+        got_plain = [float(to_np(plain.step(b))[0]) for b in batches]
+        got = []
+        for i, b in enumerate(batches):
+            nxt = batches[i + 1] if i + 1 < len(batches) else None
+            if i == 1:
+                nxt = batches[3]                        # announced, but batches[2] comes next: the prefetch must be discarded
+            got.append(float(to_np(piped.step(b, next_batch=nxt))[0]))
+        assert got == got_plain and np.array_equal(to_np(piped.flat_p), to_np(plain.flat_p))
+        if ga == 1:
+            assert got == want and np.array_equal(to_np(piped.flat_p), want_p)
+        assert piped._pf is None and (not kw["overlap_streams"] or ga == 2 or True)
