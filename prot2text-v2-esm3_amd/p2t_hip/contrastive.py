@@ -456,7 +456,7 @@ class ContrastiveTrainer:
             encs, pre = self._launch_towers(batch, segs, main.record_event())
         if self._next is not None and backward:
             # (the side streams run it behind this batch's towers: it meets the backward / optimizer tail on the caller's stream)
-            self.prefetch_towers(self._next)
+            self.prefetch_towers(self._next, getattr(self, "_next_ready", None))
 
         def text_fn():
             if pre:
@@ -626,13 +626,14 @@ class ContrastiveTrainer:
         if self.schedule is not None and self.schedule_step == "epoch":
             self.schedule.step()
 
-    def step(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    def step(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None, next_ready=None) -> torch.Tensor:
         """One micro-batch of `train_epoch` (train_contrast.py:417-465): gradients of loss / GA are accumulated, and every
         `gradient_accumulation_steps` calls clip + AdamW run.  Returns this batch's (unscaled) loss.
         next_batch (optional, already on the device): its frozen towers are enqueued on the side streams as soon as this step's
-        forward has consumed the current ones, i.e. they run beside this step's backward / optimizer tail (`prefetch_towers`)."""
+        forward has consumed the current ones, i.e. they run beside this step's backward / optimizer tail (`prefetch_towers`);
+        next_ready: an event after which its tensors are valid (None: they already are)."""
         accumulate, grad_scale, reduce, do_step = sharding.micro_step_plan(self._micro, self.gradient_accumulation_steps)
-        self._next = next_batch
+        self._next, self._next_ready = next_batch, next_ready
         loss = self.forward_backward(batch, accumulate=accumulate, grad_scale=grad_scale, reduce=reduce)
         self._next = None
         self._micro += 1

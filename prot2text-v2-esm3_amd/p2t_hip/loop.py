@@ -94,15 +94,28 @@ def train_epoch(trainer, dataloader: Iterable[Dict[str, Any]], *, rank: int = 0,
     trainer._micro = 0                             # optimizer.zero_grad(): accumulated gradients of the last epoch are dropped (:414)
     stats = EpochStats(trainer.dev) if stats is None else stats
     n = 0
-    for batch_idx, data_batch in enumerate(dataloader):
+    # one batch of look-ahead: the next batch's frozen towers are enqueued beside this step's backward / optimizer tail
+    # (ContrastiveTrainer.step(batch, next_batch)); `ready` = an event of this stream after the batch became valid on it
+    it = iter(dataloader)
+    nxt = next(it, None)
+    nxt_dev = _to_device(nxt, trainer.dev) if nxt is not None else None
+    batch_idx = 0
+    while nxt_dev is not None:
+        data_batch, cur = nxt, nxt_dev
+        nxt = next(it, None)
+        nxt_dev = _to_device(nxt, trainer.dev) if nxt is not None else None       # (the SAME dict object comes back as `cur` next turn)
+        ahead, ready = None, None
+        if nxt_dev is not None and getattr(trainer, "overlap_streams", False):
+            ahead, ready = nxt_dev, torch.cuda.current_stream().record_event()
         steps_before = trainer.step_count
-        loss = trainer.step(_to_device(data_batch, trainer.dev))
+        loss = trainer.step(cur, next_batch=ahead, next_ready=ready) if ahead is not None else trainer.step(cur)
         stats.add(loss, trainer.grad_norm if trainer.step_count > steps_before else None, batch_idx)
         n += 1
         if progress is not None:
             progress(batch_idx, data_batch)
         if n % check_every == 0:
             stats.check(log)
+        batch_idx += 1
     stats.check(log)
     loss_sum, batches, gn_sum, steps = _reduce_epoch_sums(stats, trainer.group)
     train_loss = loss_sum / batches if batches else float("nan")

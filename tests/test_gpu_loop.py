@@ -72,10 +72,11 @@ def test_impossible_loss_is_reported_and_a_nan_epoch_aborts():
     tr = _trainer()
     batches = _host_batches(3)
     lines = []
-    # a NaN in the adapter weights from batch 1 on: every later loss is NaN
+    # a NaN in the adapter weights from batch 1 on: every later loss is NaN (the epoch loop fetches one batch ahead -- batch 2 is
+    # drawn from the loader before step 1 is enqueued -- so that is where the generator plants it)
     def poisoned():
         for i, b in enumerate(batches):
-            if i == 1:
+            if i == 2:
                 tr.w1.fill_(float("nan"))
             yield b
     with pytest.raises(ValueError, match="NaN detected in the training loss of the epoch, training interrupted."):
@@ -232,4 +233,10 @@ def test_steps_pipelined_through_the_frozen_towers_equal_the_plain_sequence():
         assert got == got_plain and np.array_equal(to_np(piped.flat_p), to_np(plain.flat_p))
         if ga == 1:
             assert got == want and np.array_equal(to_np(piped.flat_p), want_p)
-        assert piped._pf is None and (not kw["overlap_streams"] or ga == 2 or True)
+        assert piped._pf is None
+    # the epoch driver looks one batch ahead by itself when the trainer runs its towers on side streams
+    import p2t_hip as P
+    ep = _trainer(overlap_streams=True)
+    rec = P.train_epoch(ep, _host_batches(4), log=lambda *_: None)
+    assert rec["batches"] == 4 and np.array_equal(to_np(ep.flat_p), want_p)
+    assert abs(rec["train_loss"] - float(np.mean(np.float32(want)))) < 1e-6
