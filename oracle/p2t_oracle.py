@@ -772,13 +772,13 @@ def _topk(x, k):
 
 
 def generate_beam(spec, W, inputs_embeds, mask, max_new_tokens, num_beams, eos_ids=(), pad_id=0, length_penalty=1.0,
-                  early_stopping=False, prec: Precision = FP32, prefix="llama_decoder."):
+                  early_stopping=False, prec: Precision = FP32, prefix="llama_decoder.", num_return_sequences=1):
     """GEN `_beam_search` (5.x vectorised form) with an empty id prompt (decoder_prompt_len 0, max_length = max_new_tokens): per
     step the top max(2, 1 + n_eos) * num_beams continuations of every prompt by accumulated log-probability; those that hit a
     stopping criterion (eos, max length) compete -- length-normalised by (cur_len + 1) ** length_penalty -- for the num_beams
     finished slots if they were among the top num_beams, the best num_beams others go on; the loop ends when no running beam can
     still beat the worst finished one (the early_stopping=False heuristic), or nothing is left to continue.
-    -> (sequences i64 [B, n] of the best hypothesis per prompt, its score f32 [B])."""
+    -> (sequences i64 [B * num_return_sequences, n]: the best hypotheses of every prompt in order, their scores f32)."""
     rows0 = _prompt_rows(inputs_embeds, mask)
     emb = W[prefix + "model.embed_tokens.weight"]
     B, nb, V, L = len(rows0), num_beams, spec.vocab_size, max_new_tokens
@@ -821,8 +821,9 @@ def generate_beam(spec, W, inputs_embeds, mask, max_new_tokens, num_beams, eos_i
         open_ = open_ & (best_running > worst_done).any(-1, keepdims=True)
         if not (open_.any() and not (done.all() and early_stopping is True) and not hits.all()):
             break
-    n = int(lens_done[:, 0].max())
-    return sequences[:, 0, :n], beam_sc[:, 0]
+    R = num_return_sequences
+    n = int(lens_done[:, :R].max())
+    return sequences[:, :R, :n].reshape(B * R, n), beam_sc[:, :R].reshape(B * R)
 
 
 # ---------------------------------------------------------------------------------------------

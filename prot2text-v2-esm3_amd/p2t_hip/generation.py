@@ -237,7 +237,7 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
     if max_new_tokens is None:
         if max_length is None:
             raise ValueError("generate() needs max_new_tokens (or max_length)")
-        max_new_tokens = max_length - (0 if input_ids is None else T)      # HF: with inputs_embeds only, max_length counts new tokens
+        max_new_tokens = max_length - T      # HF: `max_length` counts the (padded) prompt, for embeddings too (generate(): max_length -= inputs_embeds.shape[1])
     if max_new_tokens < 1:
         raise ValueError("max_new_tokens must be >= 1")
     eos_ids = _as_id_list(eos_token_id)

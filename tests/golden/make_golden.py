@@ -523,13 +523,27 @@ def run_generate(ref):
                 beams[lp] = (gb.sequences.numpy(), gb.sequences_scores.numpy())
         seq1 = g1.sequences.numpy()
         assert (seq1[1, :5] == seq0[1, :5]).all() and (seq1[1, 5:] == pad_id).all()
+        # rarer switches of the same call: two eos ids + `max_length` instead of `max_new_tokens` (greedy); beam search with
+        # early_stopping=True / "never" and two returned hypotheses per prompt
+        eos2 = [eos, int(seq0[2, 7])]
+        with torch.no_grad():
+            g2 = model.generate(**kw, max_length=T_prompt + n_new - 3, eos_token_id=eos2, do_sample=False, num_beams=1)   # counts the (padded) prompt
+            gx = {}
+            for es in (True, "never"):
+                gb = model.generate(**kw, max_new_tokens=n_new, eos_token_id=eos2, do_sample=False, num_beams=3, length_penalty=0.8, early_stopping=es,
+                                    num_return_sequences=2, output_scores=True)
+                gx[es] = (gb.sequences.numpy(), gb.sequences_scores.numpy())
+        out[f"{name}.greedy_eos2_maxlen"] = g2.sequences.numpy()
+        for es, (sq, sc) in gx.items():
+            out[f"{name}.beam3_es{es}"] = sq
+            out[f"{name}.beam3_es{es}_scores"] = sc.astype(np.float32)
         out[f"{name}.greedy"] = seq0
         out[f"{name}.greedy_logits"] = lg.astype(np.float32)
         out[f"{name}.greedy_eos"] = seq1
         for lp, (sq, sc) in beams.items():
             out[f"{name}.beam3_lp{lp}"] = sq
             out[f"{name}.beam3_lp{lp}_scores"] = sc.astype(np.float32)
-        metas[name] = dict(esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad), eos=eos, min_top2_gap=gap, weight_seed=wseed)
+        metas[name] = dict(esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad), eos=eos, eos2=eos2, min_top2_gap=gap, weight_seed=wseed)
         print(f"generate {name}: greedy {seq0[0, :6]}..., min top-2 gap {gap:.3e}, eos {eos} -> widths {seq1.shape[1]}, beams "
               f"{[(k, v[0].shape, np.round(v[1], 4).tolist()) for k, v in beams.items()]}")
     meta = dict(cases=metas, placeholder_id=placeholder_id, pad_id=pad_id, lens=lens, max_new_tokens=n_new)

@@ -229,6 +229,15 @@ def test_fp32_beam_search_vs_reference_generate(g, case):
                              do_sample=False, num_beams=3, length_penalty=float(lp), return_dict_in_generate=True, output_scores=True)
         assert np.array_equal(to_np(out.sequences), g[f"{case}.beam3_lp{lp}"]), lp
         assert np.abs(to_np(out.sequences_scores) - g[f"{case}.beam3_lp{lp}_scores"]).max() < 1e-4, lp
+    # two eos ids, early_stopping=True / "never", two hypotheses per prompt; and greedy under a `max_length` budget
+    eos2, T = meta["cases"][case]["eos2"], g["input_ids"].shape[1]
+    for es in (True, "never"):
+        out = model.generate(**_inputs(g), max_new_tokens=meta["max_new_tokens"], eos_token_id=eos2, pad_token_id=meta["pad_id"], do_sample=False,
+                             num_beams=3, length_penalty=0.8, early_stopping=es, num_return_sequences=2, return_dict_in_generate=True, output_scores=True)
+        assert np.array_equal(to_np(out.sequences), g[f"{case}.beam3_es{es}"]), es
+        assert np.abs(to_np(out.sequences_scores) - g[f"{case}.beam3_es{es}_scores"]).max() < 1e-4, es
+    seq = model.generate(**_inputs(g), max_length=T + meta["max_new_tokens"] - 3, eos_token_id=eos2, pad_token_id=meta["pad_id"], do_sample=False)
+    assert np.array_equal(to_np(seq), g[f"{case}.greedy_eos2_maxlen"])
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -212,8 +212,8 @@ def test_argument_errors():
               return_adapter_outputs=True)
     with pytest.raises(RuntimeError, match="shape mismatch"):      # no placeholder in input_ids (torch's boolean-mask assignment error)
         model(input_ids=ids, protein_input_ids=ids, protein_attention_mask=torch.ones_like(ids))
-    with pytest.raises(NotImplementedError):
-        model.generate(ids)
+    with pytest.raises(ValueError):                                 # generate() needs the protein side like forward() does
+        model.generate(ids, max_new_tokens=2)
     with pytest.raises(NotImplementedError):
         model(input_ids=ids, protein_input_ids=ids, protein_attention_mask=torch.ones_like(ids), protein_head_mask=torch.ones(1))
     with pytest.raises(IndexError):

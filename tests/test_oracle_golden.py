@@ -152,3 +152,11 @@ def test_generate_oracle_vs_reference_generate(case):
         seq, sc = O.generate_beam(llama, W, emb, g["attention_mask"], n, 3, (eos,), pad, float(lp))
         assert np.array_equal(seq, g[f"{case}.beam3_lp{lp}"]), lp
         assert np.abs(sc - g[f"{case}.beam3_lp{lp}_scores"]).max() < 1e-4, lp
+    # two eos ids and a `max_length` budget (HF counts the padded prompt in it), then early_stopping=True / "never" with two
+    # returned hypotheses per prompt
+    toks2, _ = O.generate_greedy(llama, W, emb, g["attention_mask"], n - 3, tuple(m["eos2"]), pad)
+    assert np.array_equal(toks2, g[f"{case}.greedy_eos2_maxlen"])
+    for es in (True, "never"):
+        seq, sc = O.generate_beam(llama, W, emb, g["attention_mask"], n, 3, tuple(m["eos2"]), pad, 0.8, early_stopping=es, num_return_sequences=2)
+        assert np.array_equal(seq, g[f"{case}.beam3_es{es}"]), es
+        assert np.abs(sc - g[f"{case}.beam3_es{es}_scores"]).max() < 1e-4, es
