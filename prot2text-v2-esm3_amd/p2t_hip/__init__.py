@@ -7,7 +7,8 @@ scripts/train_contrast.py), implemented on libp2t_hip.so (hand-written HIP for g
                          Esm2LlamaInstructForCausalLM, BatchInfoNCELoss, SegmentedBatchInfoNCELoss,
                          readout_embeddings, get_sequence_embeddings, get_description_embeddings,
                          teacher_forcing_forward_pass, ContrastiveTrainer,
-                         train_epoch, eval_epoch, run_epochs)         # scripts/train_contrast.py:400-519, 650-701
+                         train_epoch, eval_epoch, run_epochs,         # scripts/train_contrast.py:400-519, 650-701
+                         iterative_generation_loop, inference_epoch)  # scripts/generate_instruct.py:50-147
 
 `synth` and `specs` (pure numpy: synthetic weights/batches, tower shapes) and the host-side `data`
 (tokeniser, collater, prefetcher) and `training_state` (lr schedule, checkpoint formats) modules import
@@ -21,7 +22,8 @@ __all__ = ["specs", "synth", "Esm2LlamaInstructConfig", "ModalityAdapterConfig",
            "SegmentedBatchInfoNCELoss", "readout_embeddings", "l2_normalize", "get_sequence_embeddings",
            "get_description_embeddings", "teacher_forcing_forward_pass", "ContrastiveTrainer", "ops",
            "EsmSequenceTokenizer", "ContrastiveCollater", "DevicePrefetcher", "sort_batch_by_length", "CosineWarmupSchedule", "save_checkpoint",
-           "load_model_checkpoint", "load_optimizer_scheduler_checkpoint", "train_epoch", "eval_epoch", "run_epochs"]
+           "load_model_checkpoint", "load_optimizer_scheduler_checkpoint", "train_epoch", "eval_epoch", "run_epochs",
+           "iterative_generation_loop", "inference_epoch"]
 
 _LAZY = {
     "Esm2LlamaInstructConfig": "configuration", "ModalityAdapterConfig": "configuration",
@@ -33,7 +35,7 @@ _LAZY = {
     "EsmSequenceTokenizer": "data", "ContrastiveCollater": "data", "DevicePrefetcher": "data", "sort_batch_by_length": "data",
     "CosineWarmupSchedule": "training_state", "save_checkpoint": "training_state",
     "load_model_checkpoint": "training_state", "load_optimizer_scheduler_checkpoint": "training_state",
-    "train_epoch": "loop", "eval_epoch": "loop", "run_epochs": "loop",
+    "train_epoch": "loop", "eval_epoch": "loop", "run_epochs": "loop", "iterative_generation_loop": "loop", "inference_epoch": "loop",
 }
 
 

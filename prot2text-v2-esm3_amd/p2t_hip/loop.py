@@ -180,3 +180,50 @@ def run_epochs(trainer, train_loader, eval_loader=None, *, num_epochs: int, rank
             dist.barrier(group=trainer.group)
         history.append(rec)
     return history
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# inference (scripts/generate_instruct.py:50-147)
+# ---------------------------------------------------------------------------------------------------------------------------
+def iterative_generation_loop(rank, model, data_batch: Dict[str, Any], max_generation_length: int, num_beams: int = 1, length_penalty: float = 1.0,
+                              temperature: float = 1.0, do_sample: bool = False, top_p: float = 1.0, top_k: int = 50,
+                              eos_token_id=128009, pad_token_id: int = 128002, **generate_kwargs) -> torch.Tensor:
+    """scripts/generate_instruct.py:50-87: the batch's prompt + protein ids to `model.generate`, the new token ids back.  `rank` is the
+    device (an index or a torch.device), as upstream's `.to(rank)`; a DistributedDataParallel-style wrapper is unwrapped (`.module`)."""
+    model = getattr(model, "module", model)
+    dev = torch.device("cuda", rank) if isinstance(rank, int) else torch.device(rank)
+    to = lambda k: data_batch[k].to(dev)
+    return model.generate(inputs=to("input_ids"), attention_mask=to("attention_mask"), protein_input_ids=to("protein_input_ids"),
+                          protein_attention_mask=to("protein_attention_mask"), max_new_tokens=max_generation_length, eos_token_id=eos_token_id,
+                          pad_token_id=pad_token_id, return_dict_in_generate=False, num_beams=num_beams, length_penalty=length_penalty,
+                          temperature=temperature, do_sample=do_sample, top_p=top_p, top_k=top_k, **generate_kwargs)
+
+
+def inference_epoch(rank, model, dataloader: Iterable[Dict[str, Any]], llama_tokenizer, args: Dict[str, Any],
+                    progress: Optional[Callable] = None) -> Optional[str]:
+    """scripts/generate_instruct.py:90-147: generate for every batch of this rank's shard, decode predictions and labels with the
+    description tokenizer (`batch_decode(..., skip_special_tokens=True)`) and write
+    `generation_{save_generation_postfix_identifier}_rank{rank}.json` = {name: {"true": label, "pred": prediction}} into
+    `save_generation_dir` (returned).  Every rank generates on its own (a DistributedSampler shard per rank upstream): no collective."""
+    import json
+    import os
+    model.eval()
+    names, preds, labels = [], [], []
+    for i, data_batch in enumerate(dataloader):
+        with torch.no_grad():
+            out = iterative_generation_loop(rank, model, data_batch, args["max_generation_length"], args.get("num_beams", 1),
+                                            args.get("length_penalty", 1.0), args.get("temperature", 1.0), args.get("do_sample", False),
+                                            args.get("top_p", 1.0), args.get("top_k", 50))
+        names.extend(data_batch["name"])
+        preds.extend(llama_tokenizer.batch_decode(out.cpu(), skip_special_tokens=True))
+        labels.extend(llama_tokenizer.batch_decode(data_batch["description_input_ids"], skip_special_tokens=True))
+        if progress is not None:
+            progress(i, {"mode": "inference", "batch_maxlen_gen": out.shape[1], "device": f"rank:{rank}"})
+    if not args.get("save_generation_dir"):
+        return None
+    r = rank if isinstance(rank, int) else (torch.device(rank).index or 0)
+    path = os.path.join(args["save_generation_dir"], f"generation_{args['save_generation_postfix_identifier']}_rank{r}.json")
+    with open(path, "w") as f:
+        json.dump({n: {"true": t, "pred": p} for n, t, p in zip(names, labels, preds)}, f, indent=4)
+    print(f"Saving {path}")
+    return path

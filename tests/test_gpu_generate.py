@@ -309,3 +309,30 @@ def test_generate_refusals(g):
     ids = to_dev(np.array([[3, 4, 5, 6]], dtype=np.int64))
     out = model.llama_decoder.generate(ids, max_new_tokens=3, pad_token_id=0)
     assert out.shape == (1, 3)
+
+
+def test_inference_epoch_writes_the_reference_json(g, tmp_path):
+    """scripts/generate_instruct.py:90-147 on the fixture's batch: `iterative_generation_loop` returns the golden greedy ids, and
+    `inference_epoch` writes generation_{postfix}_rank{r}.json = {name: {"true", "pred"}} through the tokenizer's batch_decode."""
+    import p2t_hip as P
+    model = _model(g, "d64", torch.float32)
+    meta = g["meta"]
+    n, pad, eos = meta["max_new_tokens"], meta["pad_id"], meta["cases"]["d64"]["eos"]
+
+    class Tok:                                      # batch_decode(ids, skip_special_tokens=True): ids as words, specials dropped
+        def batch_decode(self, ids, skip_special_tokens=False):
+            return [" ".join(str(int(t)) for t in row if not (skip_special_tokens and int(t) in (pad, eos))) for row in ids]
+
+    batch = dict(name=["P1", "P2", "P3"], input_ids=torch.from_numpy(g["input_ids"]), attention_mask=torch.from_numpy(g["attention_mask"]),
+                 protein_input_ids=torch.from_numpy(g["protein_input_ids"]), protein_attention_mask=torch.from_numpy(g["protein_attention_mask"]),
+                 description_input_ids=torch.tensor([[7, 8, pad], [9, eos, pad], [1, 2, 3]]))
+    out = P.iterative_generation_loop(0, model, batch, n, eos_token_id=eos, pad_token_id=pad)
+    assert np.array_equal(to_np(out), g["d64.greedy_eos"])
+    args = dict(max_generation_length=n, num_beams=1, length_penalty=1.0, temperature=1.0, do_sample=False, top_p=1.0, top_k=50,
+                save_generation_dir=str(tmp_path), save_generation_postfix_identifier="test")
+    # (upstream hard-codes the Llama-3 ids 128009 / 128002, which this 512-token fixture does not have: no row stops early here)
+    path = P.inference_epoch(0, model, [batch], Tok(), args)
+    rec = json.load(open(path))
+    assert os.path.basename(path) == "generation_test_rank0.json" and list(rec) == ["P1", "P2", "P3"]
+    assert rec["P1"]["true"] == "7 8" and rec["P2"]["true"] == "9" and rec["P3"]["true"] == "1 2 3"
+    assert rec["P2"]["pred"].split() == [str(t) for t in g["d64.greedy"][1] if t not in (pad, eos)]
