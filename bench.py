@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gemm-policy", type=int, default=0, help="p2t_set_gemm_policy for A/B runs (0 = the library's default; include/p2t_hip.h)")
     ap.add_argument("--event-steps", type=int, default=3,
                     help="timed steps whose MFMA launches are bracketed by HIP events for the roofline block "
-                         "(default: the last 3 of the timed steps -- the event records cost ~1.5 % of the step when on every launch; "
+                         "(default: the last 3 of the timed steps -- the event records cost ~1.5 %% of the step when on every launch; "
                          "-1 = all, 0 = none)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="timed region on ONE HIP stream.  Default: the text tower and the encoder segments on separate HIP streams "
