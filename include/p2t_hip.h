@@ -462,7 +462,8 @@ size_t p2t_llama_decode_workspace_bytes(const p2t_llama_config* cfg, int BB, int
 /* Optional second copies of the four projection weights of a layer in the STREAM order of the decode GEMM (p2t_preshuffle_w;
  * bf16 models; built once per generate-capable model: 288 GB of HBM hold both layouts of an 8-B decoder many times over).
  * w_stream: HOST array of n_layers entries or NULL (the step then streams p2t_llama_layer's own matrices, 64-byte pieces of 16
- * rows per load instead of whole lines: 8-30 % slower per GEMM). */
+ * rows per load instead of whole lines: 8-30 % slower per GEMM).  gemm_fp8 models: the p2t_preshuffle_w_fp8 copies of the e4m3
+ * matrices (their row scales stay p2t_llama_layer's *_ws). */
 typedef struct { const void* qkv_w; const void* o_w; const void* gu_w; const void* down_w; } p2t_llama_layer_stream;
 /* One token per row: x f32 [BB, hidden] (the embedding of the token chosen last) through all layers at position
  * prompt_len[row / group] + step[0], its keys / values appended at index step[0], final RMSNorm, LM head
@@ -494,6 +495,14 @@ int p2t_gemm_nt_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, i
  * W[16 t + lane % 16][32 s + 8 (lane / 16) + e], rows N .. next multiple of 16 as zeros; out: bf16 [round_up(N, 16) * K].
  * K % 32 == 0.  Pass the result to p2t_gemm_nt_skinny with w_preshuffled = 1 (same N, K). */
 int p2t_preshuffle_w(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, p2t_stream stream);
+/* The same stream on e4m3 operands (gemm_fp8 models, section "fp8 GEMMs" of DESIGN.md): A / W e4m3 bytes [rows, K rounded up to 128, zero
+ * padded], one E8M0 scale byte per row each (p2t_quant_rows_fp8 / p2t_rmsnorm_fp8 write both for A); v_mfma_scale_f32_16x16x128_f8f6f4.
+ * lda / ldw multiples of 16.  p2t_preshuffle_w_fp8: out[(((t * K/128 + s) * 2 + h) * 64 + lane) * 16 + b] = W[16 t + lane % 16][128 s + 64 h
+ * + 16 (lane / 16) + b]; out: bytes [round_up(N, 16) * K]. */
+int p2t_gemm_nt_skinny_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
+                           int w_preshuffled, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int out_dtype, int epilogue,
+                           p2t_stream stream);
+int p2t_preshuffle_w_fp8(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, p2t_stream stream);
 /* The decode step's attention on its own (exposed so that it can be checked against the plain arithmetic): ONE query token per
  * row, q `dtype` [BB, nh, dp], over prompt_len[row / group] keys of the prompt segment and step[0] + 1 keys of the generated
  * segment (the layouts of ONE layer of p2t_kv_cache), GQA; softmax((scale) q k^T) v with f32 statistics -- log2_scores: q holds

@@ -718,7 +718,7 @@ def llama_next_token_logits(spec, W, rows, prec: Precision = FP32, prefix="llama
     token under the mask with rank r the position r (`position_ids = cumsum(attention_mask) - 1`, GEN prepare_inputs_for_generation)
     and hides the masked ones from every query, so dropping them is exact.  -> logits of the last position, f32 [B, V] (rounded to
     the model dtype first, as HF keeps `outputs.logits` in it before the f32 up-cast of `_sample`)."""
-    Wlm = prec.g(prec.q(_lm_head_weight(spec, W, prefix)))
+    Wlm = prec.q(_lm_head_weight(spec, W, prefix))            # the LM head stays in the model dtype under fp8 tower GEMMs too
     out = []
     for x in rows:
         n = x.shape[0]
@@ -727,7 +727,7 @@ def llama_next_token_logits(spec, W, rows, prec: Precision = FP32, prefix="llama
         h = np.ascontiguousarray(x[None], dtype=F32)
         for i in range(spec.num_hidden_layers):
             h = llama_layer(spec, W, i, h, bias, cos, sin, prec, prefix)
-        last = prec.g(prec.a(rms_norm(h[0, -1:], W[prefix + "model.norm.weight"], spec.rms_norm_eps)))
+        last = prec.q(rms_norm(h[0, -1:], W[prefix + "model.norm.weight"], spec.rms_norm_eps))
         out.append(prec.q((last @ Wlm.T).astype(F32))[0])
     return np.stack(out).astype(F32)
 

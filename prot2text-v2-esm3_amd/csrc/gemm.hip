@@ -243,3 +243,18 @@ extern "C" int p2t_gemm_nt_skinny(const void* A, int64_t lda, const void* W, int
                                                  (long long)N, (long long)K, epilogue);
     return r;
 }
+
+extern "C" int p2t_preshuffle_w_fp8(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, p2t_stream stream) {
+    return p2t::launch_preshuffle_fp8(W, ldw, N, K, out, (hipStream_t)stream);
+}
+
+extern "C" int p2t_gemm_nt_skinny_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale,
+                                      int w_preshuffled, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int out_dtype, int epilogue,
+                                      p2t_stream stream) {
+    P2T_REQUIRE(A && a_scale && W && w_scale && out, "p2t_gemm_nt_skinny_fp8: null argument");
+    const int r = p2t::launch_gemm_skinny_fp8(A, lda, a_scale, W, ldw, w_scale, out, ldc, M, N, K, out_dtype, epilogue, nullptr, (hipStream_t)stream,
+                                              w_preshuffled != 0);
+    if (r == P2T_ERR_UNSUPPORTED) p2t::set_error("p2t_gemm_nt_skinny_fp8: unsupported shape / epilogue (M %lld, N %lld, K %lld, epilogue %d)", (long long)M,
+                                                 (long long)N, (long long)K, epilogue);
+    return r;
+}

@@ -45,6 +45,10 @@ int launch_layernorm_fp8(const float* x, int64_t ld_x, const float* w, const flo
                          uint8_t* scale, int64_t rows, int64_t cols, float bound_w, float bound_b, uint8_t* bound_scale, hipStream_t s);
 int launch_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale, int64_t rows,
                        int64_t cols, hipStream_t s);
+// the decode step's forms for a few rows (block per row, one round trip; quant.hip)
+int launch_quant_rows_few(const void* x, int dtype, int64_t ld_x, int64_t rows, int64_t cols, void* q, int64_t ld_q, uint8_t* scale, hipStream_t s);
+int launch_rmsnorm_fp8_few(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale, int64_t rows, int64_t cols,
+                           hipStream_t s);
 int launch_gemm_fp8(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
                     int K, int n_cover, int out_dtype, int epilogue, const EpiParams& ep, int tile, hipStream_t s);
 unsigned* fault_word_ptr();            // the GPU's sticky fault word (misc.hip); nullptr if the symbol cannot be resolved
@@ -85,6 +89,10 @@ int launch_gemm_skinny_qkv_rope(const void* x, int64_t lda, const void* W, int64
 int launch_gemm_skinny(const void* x, int64_t lda, const void* W, int64_t ldw, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype,
                        int out_dtype, int epilogue, hipStream_t s, int pre = 0);
 int launch_preshuffle(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s);
+// e4m3 operands + one E8M0 scale byte per row (gemm_fp8 models): K % 128 == 0; ra: the QKV + rotation + cache-append form
+int launch_gemm_skinny_fp8(const void* x, int64_t lda, const uint8_t* xs, const void* W, int64_t ldw, const uint8_t* ws, void* out, int64_t ldc, int64_t M,
+                           int64_t N, int64_t K, int out_dtype, int epilogue, const SkinnyRope* ra, hipStream_t s, int pre);
+int launch_preshuffle_fp8(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s);
 
 int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
                        int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int dtype,

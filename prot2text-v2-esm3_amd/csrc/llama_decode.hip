@@ -487,6 +487,7 @@ __global__ void advance_kernel(int32_t* step) { step[0] += 1; }
 
 struct DecodeBuffers {
     float* x; void* h; float* qkv; void* qb; void* ao; void* act; float* inv_freq;
+    uint8_t* hq; uint8_t* hs; uint8_t* aoq; uint8_t* aos; uint8_t* actq; uint8_t* acts;      // gemm_fp8: e4m3 rows + their E8M0 scales
     int ZC, GH;
 };
 
@@ -515,6 +516,13 @@ size_t decode_plan(const p2t_llama_config* c, int BB, int Tp, int Gcap, Arena* a
     t.ao = a.take(e * (size_t)BB * QO);
     t.act = a.take(e * (size_t)BB * Fp);
     t.inv_freq = (float*)a.take(sizeof(float) * (d / 2 + 1));
+    t.hq = t.hs = t.aoq = t.aos = t.actq = t.acts = nullptr;
+    if (c->gemm_fp8) {
+        const int64_t Hq = round_up(H, 128), Fq = round_up(F, 128), QOq = round_up((int64_t)nh * d, 128);
+        t.hq = (uint8_t*)a.take((size_t)BB * Hq);    t.hs = (uint8_t*)a.take((size_t)BB);
+        t.aoq = (uint8_t*)a.take((size_t)BB * QOq);  t.aos = (uint8_t*)a.take((size_t)BB);
+        t.actq = (uint8_t*)a.take((size_t)BB * Fq);  t.acts = (uint8_t*)a.take((size_t)BB);
+    }
     if (b) *b = t;
     return a.off + 256;
 }
@@ -637,7 +645,7 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
                                      size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(c && w && w->layers && w->final_norm_w && lm_head && x_in && logits && workspace, "p2t_llama_decode_step: null argument");
     P2T_TRY(check_cache(c, cache, "p2t_llama_decode_step"));
-    P2T_REQUIRE(!c->gemm_fp8, "p2t_llama_decode_step: the decode step runs the GEMMs in the model dtype (set_gemm_dtype('model'))");
+    P2T_REQUIRE(!c->gemm_fp8 || c->dtype == P2T_BF16, "p2t_llama_decode_step: gemm_fp8 needs bf16 activations (dtype = P2T_BF16)");
     const int BB = cache->B0 * cache->group;
     const int dt = c->dtype;
     const int64_t H = c->hidden, F = c->ffn, Hp = round_up(H, 64), Fp = round_up(F, 64);
@@ -670,7 +678,52 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
         return r == P2T_ERR_UNSUPPORTED ? p2t::gemm_nt(a, st) : r;
     };
     const bool stream_w = ws_layers && dt == P2T_BF16;
-    for (int l = 0; l < c->n_layers; ++l) {
+    // gemm_fp8 models (e4m3 weights AND GEMM operands, bf16 activations elsewhere): the same step with every
+    // projection on the e4m3 stream (half the weight bytes of a step); rows are quantised by the RMSNorm / a quantise pass as in the prefill
+    const int64_t Hq = round_up(H, 128), Fq = round_up(F, 128), QOq = round_up((int64_t)nh * d, 128);
+    auto gemm8 = [&](const uint8_t* A, int64_t lda, const uint8_t* as, const void* W, const uint8_t* wsc, const void* pre, void* out, int64_t ldc,
+                     int64_t N, int64_t K, int out_dtype, int epi, const SkinnyRope* ra, hipStream_t st) {
+        const int r = launch_gemm_skinny_fp8(A, lda, as, pre ? pre : W, K, wsc, out, ldc, M, N, K, out_dtype, epi, ra, st, pre != nullptr);
+        if (r != P2T_ERR_UNSUPPORTED || ra) return r;
+        GemmArgs g{A, lda, W, K, nullptr, out, ldc, nullptr, M, N, K, P2T_FP8, out_dtype, epi, 0, 1, -1, 0.f, 0, 0};
+        g.a_scale = as; g.w_scale = wsc;
+        if (epi == P2T_EPI_STORE_F32) g.n_zero = (int)N;
+        return p2t::gemm_nt(g, st);
+    };
+    for (int l = 0; c->gemm_fp8 && l < c->n_layers; ++l) {
+        const p2t_llama_layer& L = w->layers[l];
+        P2T_REQUIRE(L.qkv_ws && L.o_ws && L.gu_ws && L.down_ws, "p2t_llama_decode_step: gemm_fp8 needs the row scales of layer %d", l);
+        P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_decode_step: q_norm_w and k_norm_w go together (layer %d)", l);
+        const int fused_prefill = !L.q_norm_w && (d == 64 || d == 128);
+        const p2t_llama_layer_stream* S = ws_layers ? ws_layers + l : nullptr;
+        const size_t per_g = (size_t)BB * nkv * cache->G * dp;
+        P2T_TRY(launch_rmsnorm_fp8_few(b.x, H, L.ln1_w, c->rms_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        bool roped = false;
+        if (fused_prefill && g_decode_fusion.load()) {
+            SkinnyRope ra;
+            ra.inv_freq = inv_freq; ra.prompt_len = cache->prompt_len; ra.step = cache->step; ra.group = cache->group;
+            ra.nh = nh; ra.nkv = nkv; ra.d = d; ra.G = cache->G; ra.q_scale = q_fold;
+            ra.q = b.qb; ra.k = (bf16_t*)cache->k_gen + per_g * l; ra.vt = (bf16_t*)cache->vt_gen + per_g * l;
+            const int r = gemm8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, S ? S->qkv_w : nullptr, nullptr, 0, NQKV, Hq, dt, 0, &ra, s);
+            if (r != P2T_ERR_UNSUPPORTED) { P2T_TRY(r); roped = true; }
+        }
+        if (!roped) {
+            P2T_TRY(gemm8(b.hq, Hq, b.hs, L.qkv_w, L.qkv_ws, S ? S->qkv_w : nullptr, b.qkv, NQKV, NQKV, Hq, P2T_F32, P2T_EPI_STORE_F32, nullptr, s));
+            const unsigned grid = (unsigned)ceil_div((int64_t)BB * (nh + 2 * nkv), 4);
+            rope_append_kernel<bf16_t><<<grid, 256, 0, s>>>(b.qkv, NQKV, inv_freq, L.q_norm_w, L.k_norm_w, c->rms_norm_eps, cache->prompt_len, cache->step,
+                                                            cache->group, (bf16_t*)b.qb, (bf16_t*)cache->k_gen + per_g * l, (bf16_t*)cache->vt_gen + per_g * l,
+                                                            BB, nh, nkv, d, dp, cache->G, q_fold, d == 128 && !L.q_norm_w, !fused_prefill);
+            P2T_LAUNCH_CHECK();
+        }
+        P2T_TRY(launch_attn_decode_t<bf16_t>(b, cache, l, BB, nh, nkv, d, dp, c_exp, 1, QO, s));
+        P2T_TRY(launch_quant_rows_few(b.ao, dt, QO, M, (int64_t)nh * d, b.aoq, QOq, b.aos, s));
+        P2T_TRY(gemm8(b.aoq, QOq, b.aos, L.o_w, L.o_ws, S ? S->o_w : nullptr, b.x, H, H, QOq, P2T_F32, P2T_EPI_RESID, nullptr, s));
+        P2T_TRY(launch_rmsnorm_fp8_few(b.x, H, L.ln2_w, c->rms_norm_eps, b.hq, Hq, b.hs, M, H, s));
+        P2T_TRY(gemm8(b.hq, Hq, b.hs, L.gu_w, L.gu_ws, S ? S->gu_w : nullptr, b.act, Fp, 2 * F, Hq, dt, P2T_EPI_SWIGLU, nullptr, s));
+        P2T_TRY(launch_quant_rows_few(b.act, dt, Fp, M, F, b.actq, Fq, b.acts, s));
+        P2T_TRY(gemm8(b.actq, Fq, b.acts, L.down_w, L.down_ws, S ? S->down_w : nullptr, b.x, H, H, Fq, P2T_F32, P2T_EPI_RESID, nullptr, s));
+    }
+    for (int l = 0; !c->gemm_fp8 && l < c->n_layers; ++l) {
         const p2t_llama_layer& L = w->layers[l];
         P2T_REQUIRE(!L.q_norm_w == !L.k_norm_w, "p2t_llama_decode_step: q_norm_w and k_norm_w go together (layer %d)", l);
         const int fused_prefill = !L.q_norm_w && (d == 64 || d == 128);

@@ -86,6 +86,105 @@ int launch_quant_rows(const void* x, int dtype, int64_t ld_x, int64_t rows, int6
     return P2T_OK;
 }
 
+// ---- a handful of rows (one decode step of a gemm_fp8 model): one BLOCK per row, the row in registers, every load requested up
+// front (the wave-per-row kernels above walk a 14 336-wide row in 28 dependent trips: 12 us; this form: one) ----
+__device__ __forceinline__ float block_max4(float v, float* red) {            // 4 waves; every thread gets the maximum
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// NV chunks of 8 elements per thread: cols <= NV * 2048.  Bit-identical to quant_rows_kernel (a maximum has no order).
+template <typename Tin, int NV>
+__global__ void __launch_bounds__(256) quant_rows_few_kernel(const Tin* __restrict__ x, int64_t ld_x, int cols, uint8_t* __restrict__ q, int64_t ld_q,
+                                                             uint8_t* __restrict__ scale) {
+    __shared__ float red[4];
+    const Tin* xr = x + (int64_t)blockIdx.x * ld_x;
+    float v[NV][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c + 8 <= cols) {
+            if constexpr (sizeof(Tin) == 2) { load8(xr + c, v[i]); } else { float a[4], b[4]; load4(xr + c, a); load4(xr + c + 4, b);
+                for (int j = 0; j < 4; ++j) { v[i][j] = a[j]; v[i][4 + j] = b[j]; } }
+        } else {
+            for (int j = 0; j < 8; ++j) v[i][j] = c + j < cols ? to_f32(xr[c + j]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j]));
+    amax = block_max4(amax, red);
+    const int E = e8m0_of_amax(amax);
+    const float inv = pow2_neg(E);
+    if (threadIdx.x == 0) scale[blockIdx.x] = (uint8_t)E;
+    uint8_t* qr = q + (int64_t)blockIdx.x * ld_q;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < ld_q)
+            *reinterpret_cast<uint2*>(qr + c) = make_uint2(pack_fp8x4(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv),
+                                                           pack_fp8x4(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv));
+    }
+}
+
+int launch_quant_rows_few(const void* x, int dtype, int64_t ld_x, int64_t rows, int64_t cols, void* q, int64_t ld_q, uint8_t* scale, hipStream_t s) {
+    if (rows == 0) return P2T_OK;
+    if (ld_q % 8 || ld_q < cols || ld_x % 8 || ld_q > 8 * 2048) return launch_quant_rows(x, dtype, ld_x, rows, cols, q, ld_q, scale, s);
+#define P2T_QF(NV)                                                                                                                 \
+    do {                                                                                                                           \
+        if (dtype == P2T_BF16) quant_rows_few_kernel<bf16_t, NV><<<(unsigned)rows, 256, 0, s>>>((const bf16_t*)x, ld_x, (int)cols, (uint8_t*)q, ld_q, scale); \
+        else quant_rows_few_kernel<float, NV><<<(unsigned)rows, 256, 0, s>>>((const float*)x, ld_x, (int)cols, (uint8_t*)q, ld_q, scale);                   \
+    } while (0)
+    if (ld_q <= 2048) P2T_QF(1); else if (ld_q <= 4096) P2T_QF(2); else if (ld_q <= 8192) P2T_QF(4); else P2T_QF(8);
+#undef P2T_QF
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+// RMSNorm of a few rows of the f32 stream written as e4m3 + E8M0 (norm_fp8_kernel<.., RMS>'s arithmetic, another order of the sum)
+template <int NV>
+__global__ void __launch_bounds__(256) rmsnorm_fp8_rows_kernel(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ w, float eps,
+                                                               uint8_t* __restrict__ q, int64_t ld_q, uint8_t* __restrict__ scale, int cols) {
+    __shared__ float red[4];
+    const float* xr = x + (int64_t)blockIdx.x * ld_x;
+    float v[NV][4], wv[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c < cols) { load4(xr + c, v[i]); load4(w + c, wv[i]); }
+        else { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; wv[i][0] = wv[i][1] = wv[i][2] = wv[i][3] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    const float rstd = rsqrtf(block_sum<4>(s, red) / (float)cols + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[i][j] = wv[i][j] * (v[i][j] * rstd);
+            amax = fmaxf(amax, fabsf(v[i][j]));
+        }
+    amax = block_max4(amax, red);
+    const int E = e8m0_of_amax(amax);
+    const float inv = pow2_neg(E);
+    if (threadIdx.x == 0) scale[blockIdx.x] = (uint8_t)E;
+    uint8_t* qr = q + (int64_t)blockIdx.x * ld_q;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c < cols) *reinterpret_cast<unsigned*>(qr + c) = pack_fp8x4(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
+        else if (c < ld_q) *reinterpret_cast<unsigned*>(qr + c) = 0u;
+    }
+}
+
 // LayerNorm / RMSNorm with the row kept in registers (norm.hip's structure), output quantised in place.
 template <int NV, bool RMS>
 __global__ void __launch_bounds__(256) norm_fp8_kernel(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ w,
@@ -197,6 +296,19 @@ int launch_rmsnorm_fp8(const float* x, int64_t ld_x, const float* w, float eps, 
     if (rows == 0) return P2T_OK;
     P2T_REQUIRE(cols % 4 == 0 && ld_q % 4 == 0 && ld_q >= cols, "rmsnorm (fp8 output): cols and ld_q must be multiples of 4");
     return launch_norm_fp8_t<true>(x, ld_x, w, nullptr, eps, (uint8_t*)q, ld_q, scale, rows, cols, 0.f, 0.f, nullptr, s);
+}
+
+// the decode step's form (a few rows): block per row; wider rows than 8192 take the wave-per-row kernel
+int launch_rmsnorm_fp8_few(const float* x, int64_t ld_x, const float* w, float eps, void* q, int64_t ld_q, uint8_t* scale, int64_t rows, int64_t cols,
+                           hipStream_t s) {
+    if (rows == 0) return P2T_OK;
+    const int64_t span = ld_q > cols ? ld_q : cols;
+    if (cols % 4 || ld_q % 4 || ld_q < cols || span > 8 * 1024) return launch_rmsnorm_fp8(x, ld_x, w, eps, q, ld_q, scale, rows, cols, s);
+#define P2T_RF(NV) rmsnorm_fp8_rows_kernel<NV><<<(unsigned)rows, 256, 0, s>>>(x, ld_x, w, eps, (uint8_t*)q, ld_q, scale, (int)cols)
+    if (span <= 1024) P2T_RF(1); else if (span <= 2048) P2T_RF(2); else if (span <= 4096) P2T_RF(4); else P2T_RF(8);
+#undef P2T_RF
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
 }
 
 }  // namespace p2t

@@ -74,10 +74,11 @@ def filter_logits(scores: torch.Tensor, temperature: float = 1.0, top_k: Optiona
 
 # ---------------------------------------------------------------------------------------------------------------------------
 def preshuffle(w: torch.Tensor, n: int) -> torch.Tensor:
-    """bf16 [>= n, K] -> the stream order of the decode GEMM (p2t_preshuffle_w): 1 KB per (16 rows, 32 of K), whole-line loads."""
+    """bf16 [>= n, K] (or e4m3 bytes as uint8, K % 128 == 0) -> the stream order of the decode GEMM (p2t_preshuffle_w[_fp8]): the
+    1 KB one MFMA consumes is contiguous, whole-line loads."""
     K = w.shape[1]
-    out = torch.empty((round_up(n, 16) * K,), dtype=torch.bfloat16, device=w.device)
-    call("p2t_preshuffle_w", ptr(w), w.stride(0), n, K, ptr(out), stream())
+    out = torch.empty((round_up(n, 16) * K,), dtype=w.dtype, device=w.device)
+    call("p2t_preshuffle_w_fp8" if w.dtype == torch.uint8 else "p2t_preshuffle_w", ptr(w), w.stride(0), n, K, ptr(out), stream())
     return out
 
 
@@ -87,7 +88,7 @@ def stream_weights(decoder):
     m, s = decoder.model, decoder.spec
     e = m.ensure_engine(s.num_hidden_layers)
     lm = decoder._lm_head_padded()
-    key = (id(e), lm.data_ptr())
+    key = (id(e), lm.data_ptr(), bool(m.gemm_fp8))
     st = getattr(m, "_stream_engine", None)
     if st is not None and st["key"] == key:
         return st
@@ -110,8 +111,6 @@ class DecodeEngine:
 
     def __init__(self, decoder, B0: int, group: int, T: int, max_new_tokens: int, stream_copy: bool = True):
         m, s = decoder.model, decoder.spec
-        if m.gemm_fp8:
-            raise ValueError("generation runs the decoder GEMMs in the model dtype: call set_gemm_dtype('model') first")
         if s.hidden_size % 64:
             raise ValueError("the LM head path needs hidden_size % 64 == 0")
         self.decoder, self.spec, self.dtype = decoder, s, m.dtype

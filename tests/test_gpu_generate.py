@@ -178,6 +178,41 @@ def test_skinny_gemm_vs_numpy(shape):
         _lib.call("p2t_gemm_nt_skinny", ptr(xd), K, ptr(wd), K, 0, ptr(out), ldc, 65, N, K, _lib.F32, _lib.EPI_STORE, stream())
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 128), (5, 96, 256), (8, 4096, 4096), (16, 6144, 4096), (19, 1000, 512), (32, 2048, 1792), (64, 640, 384)])
+def test_skinny_gemm_fp8_vs_numpy_on_the_same_quantised_operands(shape):
+    """p2t_gemm_nt_skinny_fp8 (the decode step's GEMM of gemm_fp8 models: e4m3 operands, one E8M0 scale per row, block-scaled MFMA)
+    against numpy on the de-quantised operands; row-major weights and the pre-shuffled stream copy give the same bits."""
+    from p2t_hip import _lib, ops
+    from p2t_hip.generation import preshuffle
+    from p2t_hip.ops import ptr, stream
+    M, N, K = shape
+    a = rnd(52, "s8.a", (M, K), 1.0) * np.exp(rnd(52, "s8.as", (M, 1), 2.0)).astype(np.float32)
+    w = rnd(52, "s8.w", (N, K), 0.5) * np.exp(rnd(52, "s8.ws", (N, 1), 2.0)).astype(np.float32) / np.float32(np.sqrt(K))
+    a8, sa = ops.quant_rows_fp8(to_dev(a))
+    w8, sw = ops.quant_rows_fp8(to_dev(w))
+    Kq = a8.shape[1]
+    ref = O.quant_rows_e4m3(a)[0] @ O.quant_rows_e4m3(w)[0].T
+    ldc = (N + 3) // 4 * 4
+    outs = []
+    for pre, wt in ((0, w8), (1, preshuffle(w8, N))):
+        out = torch.full((M, ldc), 7.0, dtype=torch.float32, device=dev())
+        _lib.call("p2t_gemm_nt_skinny_fp8", ptr(a8), Kq, ptr(sa), ptr(wt), Kq, ptr(sw), pre, ptr(out), ldc, M, N, Kq, _lib.F32, _lib.EPI_STORE, stream())
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and (to_np(outs[0])[:, N:] == 7.0).all()
+    observe(f"skinny_fp8[{M}x{N}x{K}].f32", rel(to_np(outs[0])[:, :N], ref), 3e-5)
+    base = rnd(52, "s8.r", (M, ldc), 1.0)
+    acc = to_dev(base.copy())
+    _lib.call("p2t_gemm_nt_skinny_fp8", ptr(a8), Kq, ptr(sa), ptr(w8), Kq, ptr(sw), 0, ptr(acc), ldc, M, N, Kq, _lib.F32, _lib.EPI_RESID, stream())
+    assert np.allclose(to_np(acc)[:, :N], base[:, :N] + to_np(outs[0])[:, :N], rtol=0, atol=1e-5 * np.abs(ref).max())
+    if N % 64 == 0:
+        F = N // 2
+        blocks = to_np(outs[0])[:, :N].reshape(M, N // 64, 2, 32)
+        gate, up = blocks[:, :, 0].reshape(M, F), blocks[:, :, 1].reshape(M, F)
+        act = torch.zeros((M, F), dtype=torch.bfloat16, device=dev())
+        _lib.call("p2t_gemm_nt_skinny_fp8", ptr(a8), Kq, ptr(sa), ptr(w8), Kq, ptr(sw), 0, ptr(act), F, M, N, Kq, _lib.BF16, _lib.EPI_SWIGLU, stream())
+        assert rel(to_np(act).astype(np.float32), gate / (1.0 + np.exp(-gate)) * up) < 4e-3
+
+
 def test_greedy_select_ties_and_finished_rows():
     from p2t_hip import _lib, ops
     from p2t_hip.ops import ptr, stream
@@ -336,3 +371,34 @@ def test_inference_epoch_writes_the_reference_json(g, tmp_path):
     assert os.path.basename(path) == "generation_test_rank0.json" and list(rec) == ["P1", "P2", "P3"]
     assert rec["P1"]["true"] == "7 8" and rec["P2"]["true"] == "9" and rec["P3"]["true"] == "1 2 3"
     assert rec["P2"]["pred"].split() == [str(t) for t in g["d64.greedy"][1] if t not in (pad, eos)]
+
+
+@pytest.mark.parametrize("case", ["d64", "d128", "d16"])
+def test_fp8_gemm_model_generates_like_its_own_cacheless_forward(g, case):
+    """`set_gemm_dtype("fp8")` models: the decode step streams e4m3 weights (p2t_gemm_nt_skinny_fp8, rows quantised
+    by the RMSNorm / a quantise pass as in the prefill).  Per-step logits against the model's own cache-less fp8 forward over prompt
+    + generated ids, and against the fp8 oracle fed the same tokens; stream copies == row-major weights bit for bit."""
+    model = _model(g, case, torch.bfloat16)
+    model.set_gemm_dtype("fp8")
+    meta = g["meta"]
+    m = meta["cases"][case]
+    n, pad = 6, meta["pad_id"]
+    kw = dict(max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True, output_logits=True)
+    out = model.generate(**_inputs(g), **kw)
+    out_n = model.generate(**_inputs(g), **kw, stream_copy=False, use_graph=False)
+    toks, lg = to_np(out.sequences), to_np(torch.stack(out.logits, 0))
+    assert torch.equal(out.sequences, out_n.sequences) and torch.equal(torch.stack(out.logits, 0), torch.stack(out_n.logits, 0))
+    emb, mask = model(input_ids=to_dev(g["input_ids"]), attention_mask=to_dev(g["attention_mask"]), protein_input_ids=to_dev(g["protein_input_ids"]),
+                      protein_attention_mask=to_dev(g["protein_attention_mask"]), return_decoder_inputs=True)
+    dec = model.llama_decoder
+    for b in range(toks.shape[0]):
+        valid = to_np(mask)[b] != 0
+        row = torch.cat([emb[b][torch.from_numpy(valid).to(emb.device)], dec.model.embed(to_dev(toks[b:b + 1, :-1]))[0]], 0)[None]
+        full = to_np(dec(inputs_embeds=row).logits.float())[0]
+        n0 = int(valid.sum())
+        observe(f"generate[{case}].fp8_cache_vs_full_forward.row{b}", rel(lg[:, b], full[n0 - 1:n0 - 1 + n]), 8e-2)
+    model.set_gemm_dtype("model")
+    esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
+    W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
+    _, ref = O.generate_greedy(llama, W, to_np(emb), to_np(mask), n, (), pad, prec=O.FP8, forced=toks)
+    observe(f"generate[{case}].fp8_vs_fp8oracle.logits", rel(lg, ref), 1e-1)
