@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_${TAG}_generate
 mkdir -p $OUT
 export TMPDIR=/tmp
 : > $OUT/generate_bench.log
-for args in "8 64" "32 64" "1 64" "8 32 4"; do
+for args in "8 64" "32 64" "1 64" "8 32 4" "8 64 1 fp8" "32 64 1 fp8"; do
     timeout -k 10 300 python3 tools/generate_bench.py $args 2>$OUT/bench.err | grep -E "^generate|^prompt" >> $OUT/generate_bench.log || { echo "generate_bench $args failed"; tail -5 $OUT/bench.err; exit 1; }
 done
 cut -c1-260 $OUT/generate_bench.log
