@@ -63,6 +63,8 @@ def parse():
                          "(ContrastiveTrainer(overlap_streams=True): co-scheduled kernels fill each other's partial rounds, +2-3 %%); the "
                          "roofline block's per-kernel event times always come from a separate single-stream pass after the timed region")
     ap.add_argument("--overlap", action="store_true", help="(default since round 3; accepted for old command lines)")
+    ap.add_argument("--no-generate-check", action="store_true",
+                    help="skip the extra (untimed-for-`value`) measurement of `generate`: ms per KV-cache decode step at 8 prompts and its HBM roofline")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not enqueue the next step's frozen towers beside this step's backward / optimizer tail (the timed default does)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="pairs of the benchmarked config in the CPU-baseline sample")
@@ -230,6 +232,41 @@ def pmc_traffic(cfg_name, batch, family="gemm_nt_mfma*"):
         except (KeyError, ValueError, OSError):
             continue
     return None
+
+
+def generate_check(model, llama, Tp, dev, B=8, n_prompt=64, n_new=33):
+    """ms per KV-cache decode step of `model.generate` (greedy) and the step's HBM roofline fraction."""
+    import torch
+    from p2t_hip import synth
+    rs = np.random.RandomState(0)
+    T = Tp + n_prompt
+    ids = rs.randint(0, 128000, size=(B, T)).astype(np.int64)
+    ids[:, 16:16 + Tp] = model.config.placeholder_id
+    pid, pmask = synth.protein_batch(5, B, Tp)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    kw = dict(inputs=t(ids), attention_mask=torch.ones((B, T), dtype=torch.int64, device=dev), protein_input_ids=t(pid),
+              protein_attention_mask=t(pmask), eos_token_id=None, pad_token_id=128002, do_sample=False)
+    model.eval()
+    model.generate(**kw, max_new_tokens=3)                       # engines, stream copies of the weights, lazy initialisation
+    torch.cuda.synchronize()
+    times = []
+    for n in (1, n_new):
+        t0 = time.perf_counter()
+        model.generate(**kw, max_new_tokens=n)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = (times[1] - times[0]) / (n_new - 1)
+    H, F, L, V = llama.hidden_size, llama.intermediate_size, llama.num_hidden_layers, llama.vocab_size
+    nh, nkv, d = llama.num_attention_heads, llama.num_key_value_heads, llama.head_dim
+    w_bytes = 2 * (L * ((nh + 2 * nkv) * d * H + nh * d * H + 3 * H * F) + V * H)
+    kv_bytes = 2 * 2 * L * nkv * d * B * (T + n_new / 2)
+    # drop the 15 GB of stream copies again: the legs after this one run the CPU oracle beside the GPU model
+    model.llama_decoder.model._stream_engine = None
+    torch.cuda.empty_cache()
+    return {"workload": f"{B} prompts x {T} tokens ({Tp} protein placeholders), greedy, all {L} decoder layers + LM head per token",
+            "ms_per_decode_step": round(dt * 1e3, 3), "tokens_per_s": round(B / dt, 1), "prompt_phase_ms": round(times[0] * 1e3, 1),
+            "step_bytes_gb": round((w_bytes + kv_bytes) / 1e9, 2), "hbm_tb_per_s": round((w_bytes + kv_bytes) / dt / 1e12, 2),
+            "frac_of_hbm_peak": round((w_bytes + kv_bytes) / dt / 8e12, 3)}
 
 
 def spawn_ranks(n: int) -> int:
@@ -486,6 +523,16 @@ def main():
         if one_stream_rate is not None:
             # the same step on ONE stream, taken from the event pass above (includes the ~1.5 % cost of the event records)
             out["config"]["one_stream_check"] = {"samples_per_s": round(one_stream_rate, 2)}
+        if world == 1 and not args.no_generate_check and not args.no_batch64_check and args.config in ("cfg3", "cfg4"):
+            # `generate` of the same model (reference models/modeling_esm2llama_instruct.py:217-251): 8 prompts of T_p placeholders + 64
+            # tokens, greedy; per decode step = (time of 33 new tokens - time of 1) / 32.  HBM-bound: every decoder weight + the KV cache
+            # once per step.  Not part of `value`; a failure here is reported, never fatal to the headline.
+            try:
+                out["config"]["generate_check"] = generate_check(model, llama, Tp, dev)
+            except Exception as e:                                      # noqa: BLE001
+                out["config"]["generate_check"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                model.train(not args.eval_mode)
         if world == 1 and not args.no_cpu_baseline:
             # forward + loss only (eval mode): the quantity the CPU baseline below measures
             trainer.evaluate(batch)

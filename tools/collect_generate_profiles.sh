@@ -26,6 +26,6 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MF
     echo "== pmc $name"
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc/$name --output-format csv -- python3 tools/generate_bench.py 8 12 > $OUT/pmc_$name.log 2>&1 || { echo "pmc $name failed"; tail -5 $OUT/pmc_$name.log; exit 1; }
 done
-python3 tools/pmc_traffic.py $OUT/pmc $OUT/pmc_traffic.json "$TAG generate 8 prompts" cfg3 | head -40
+python3 tools/pmc_traffic.py $OUT/pmc $OUT/pmc_traffic.json "$TAG generate 8 prompts" generate/8 | head -40
 find $OUT/pmc -name "*.csv" -size +20M -delete
 du -sh $OUT

@@ -72,7 +72,8 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
     from p2t_hip import specs
     m = re.search(r"--batch\s+(\d+)", label)
-    workload = f"{cfg}/{int(m.group(1)) if m else specs.CONFIGS[cfg][3]}"   # config / per-GPU batch (bench.py's default unless the label carries --batch N)
+    # config / per-GPU batch (bench.py's default unless the label carries --batch N); any other name (e.g. "generate/8") is kept as it is
+    workload = f"{cfg}/{int(m.group(1)) if m else specs.CONFIGS[cfg][3]}" if cfg in specs.CONFIGS else cfg
     merged = defaultdict(dict)
     for sub in sorted(os.listdir(root)):
         for fam, counters in read_pass(os.path.join(root, sub)).items():
