@@ -590,7 +590,7 @@ class LlamaTextModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
         if position_ids is not None or past_key_values is not None or use_cache:
-            raise NotImplementedError("position_ids / KV cache belong to generation, which is out of scope")
+            raise NotImplementedError("position_ids / past_key_values are not arguments of this forward: the KV cache lives inside `generate` (p2t_hip/generation.py)")
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         if output_attentions:
@@ -720,7 +720,7 @@ class LlamaDecoder(nn.Module):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         if position_ids is not None or past_key_values is not None or use_cache or cache_position is not None:
-            raise NotImplementedError("position_ids / KV cache / cache_position belong to generation, which is out of scope")
+            raise NotImplementedError("position_ids / past_key_values / cache_position are not arguments of this forward: the KV cache lives inside `generate` (p2t_hip/generation.py)")
         if output_attentions or output_hidden_states:
             raise NotImplementedError("output_attentions / output_hidden_states are not available from the fused decoder")
         s, m = self.spec, self.model
