@@ -471,13 +471,12 @@ typedef struct { const void* qkv_w; const void* o_w; const void* gu_w; const voi
  * (HF keeps the logits in the model dtype and up-casts the last position to f32: generation/utils.py `_sample`); step[0] += 1.
  * lm_head_preshuffled: lm_head is the p2t_preshuffle_w copy (ld_head ignored).
  * Every length is read on the device: the call can be captured into a HIP graph and replayed. */
+enum { P2T_DECODE_NO_ROPE_FUSION = 1 };     /* flags: run the QKV projection and the rotation + cache append as two launches even where the
+                                               fused epilogue applies (bf16, head_dim 64 / 128, no q/k norm): the same arithmetic, bit for bit */
 int p2t_llama_decode_step(const p2t_llama_config* cfg, const p2t_llama_weights* w, const p2t_llama_layer_stream* w_stream,
                           const void* lm_head, int64_t ld_head, int lm_head_preshuffled, const p2t_kv_cache* cache,
-                          const float* x, void* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes,
+                          const float* x, void* logits, int64_t ld_logits, int flags, void* workspace, size_t workspace_bytes,
                           p2t_stream stream);
-/* Tests: 0 = the decode step runs the QKV projection and the rotation + cache append as two launches even where the fused
- * epilogue applies (bf16, head_dim 64 / 128, no q/k norm); 1 (default) = fused.  Same arithmetic, bit for bit. */
-int p2t_set_decode_fusion(int on);
 /* Greedy choice with HF's finished-row rule: next[r] = finished[r] ? pad_id : argmax(logits[r, :V]) (lowest index among equal
  * maxima, torch.argmax), out_tokens[r, step[0]] = next[r], finished[r] |= next[r] in eos_ids.  eos_ids i64 [n_eos], finished
  * i32 [BB], next_tokens i64 [BB], out_tokens i64 [BB, ld_tokens >= G]: all on the device. */

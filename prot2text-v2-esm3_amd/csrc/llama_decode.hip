@@ -16,12 +16,8 @@
 #include "common.h"
 #include "kernels.h"
 
-#include <atomic>
-
 namespace p2t {
 namespace {
-
-std::atomic<int> g_decode_fusion{1};        // p2t_set_decode_fusion (tests): 0 = projection and rotation + append as two launches
 
 // ---------------------------------------------------------------------------------------------
 // compaction of the prompt rows
@@ -641,9 +637,10 @@ extern "C" size_t p2t_llama_decode_workspace_bytes(const p2t_llama_config* cfg, 
 }
 
 extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_weights* w, const p2t_llama_layer_stream* ws_layers,
-                                     const void* lm_head, int64_t ld_head, int lm_head_preshuffled, const p2t_kv_cache* cache, const float* x_in, void* logits, int64_t ld_logits, void* workspace,
+                                     const void* lm_head, int64_t ld_head, int lm_head_preshuffled, const p2t_kv_cache* cache, const float* x_in, void* logits, int64_t ld_logits, int flags, void* workspace,
                                      size_t workspace_bytes, p2t_stream stream) {
     P2T_REQUIRE(c && w && w->layers && w->final_norm_w && lm_head && x_in && logits && workspace, "p2t_llama_decode_step: null argument");
+    const bool fuse_rope = !(flags & P2T_DECODE_NO_ROPE_FUSION);
     P2T_TRY(check_cache(c, cache, "p2t_llama_decode_step"));
     P2T_REQUIRE(!c->gemm_fp8 || c->dtype == P2T_BF16, "p2t_llama_decode_step: gemm_fp8 needs bf16 activations (dtype = P2T_BF16)");
     const int BB = cache->B0 * cache->group;
@@ -699,7 +696,7 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
         const size_t per_g = (size_t)BB * nkv * cache->G * dp;
         P2T_TRY(launch_rmsnorm_fp8_few(b.x, H, L.ln1_w, c->rms_norm_eps, b.hq, Hq, b.hs, M, H, s));
         bool roped = false;
-        if (fused_prefill && g_decode_fusion.load()) {
+        if (fused_prefill && fuse_rope) {
             SkinnyRope ra;
             ra.inv_freq = inv_freq; ra.prompt_len = cache->prompt_len; ra.step = cache->step; ra.group = cache->group;
             ra.nh = nh; ra.nkv = nkv; ra.d = d; ra.G = cache->G; ra.q_scale = q_fold;
@@ -729,7 +726,7 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
         const int fused_prefill = !L.q_norm_w && (d == 64 || d == 128);
         P2T_TRY(launch_rmsnorm_few_rows(b.x, H, L.ln1_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
         bool roped = false;
-        if (fused_prefill && dt == P2T_BF16 && g_decode_fusion.load()) {   // projection + rotation + cache append in one launch (SK_QKV_ROPE)
+        if (fused_prefill && dt == P2T_BF16 && fuse_rope) {   // projection + rotation + cache append in one launch (SK_QKV_ROPE)
             const size_t per_g = (size_t)BB * nkv * cache->G * dp;
             SkinnyRope ra;
             ra.inv_freq = inv_freq; ra.prompt_len = cache->prompt_len; ra.step = cache->step; ra.group = cache->group;
@@ -831,9 +828,4 @@ extern "C" int p2t_attention_decode(const void* q, const void* k_prompt, const v
     if (dtype == P2T_BF16) return launch_attn_decode_t<bf16_t>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 1, ld_out, s, use_mfma != 0);
     P2T_REQUIRE(use_mfma <= 0, "p2t_attention_decode: the matrix-pipe kernel is bf16 only");
     return launch_attn_decode_t<float>(b, &kc, 0, BB, nh, nkv, head_dim, dp, c_exp, 0, ld_out, s);
-}
-
-extern "C" int p2t_set_decode_fusion(int on) {
-    g_decode_fusion.store(on != 0);
-    return P2T_OK;
 }

@@ -132,14 +132,13 @@ SIGNATURES = {
     "p2t_llama_prefill": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, vp, i32, i32, C.POINTER(KvCacheC), vp, vp, sz, vp]),
     "p2t_llama_decode_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32, i32]),
     "p2t_llama_decode_step": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), C.POINTER(LlamaLayerStreamC), vp, i64, i32, C.POINTER(KvCacheC), vp, vp, i64,
-                              vp, sz, vp]),
+                              i32, vp, sz, vp]),
     "p2t_greedy_select": (i32, [vp, i32, i64, i32, i32, vp, i32, i64, vp, vp, vp, i64, vp, i32, vp]),
     "p2t_attention_decode": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp, i64, vp]),
     "p2t_gemm_nt_skinny": (i32, [vp, i64, vp, i64, i32, vp, i64, i64, i64, i64, i32, i32, vp]),
     "p2t_preshuffle_w": (i32, [vp, i64, i64, i64, vp, vp]),
     "p2t_preshuffle_w_fp8": (i32, [vp, i64, i64, i64, vp, vp]),
     "p2t_gemm_nt_skinny_fp8": (i32, [vp, i64, vp, vp, i64, vp, i32, vp, i64, i64, i64, i64, i32, i32, vp]),
-    "p2t_set_decode_fusion": (i32, [i32]),
     "p2t_kv_reorder": (i32, [C.POINTER(LlamaConfigC), C.POINTER(KvCacheC), vp, vp, vp, vp]),
     "p2t_llama_tape_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
     "p2t_llama_train_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),

@@ -109,8 +109,9 @@ def stream_weights(decoder):
 class DecodeEngine:
     """Cache + buffers of ONE generate() call: B0 prompts, `group` rows per prompt (beams), capacities Tp / G (multiples of 64)."""
 
-    def __init__(self, decoder, B0: int, group: int, T: int, max_new_tokens: int, stream_copy: bool = True):
+    def __init__(self, decoder, B0: int, group: int, T: int, max_new_tokens: int, stream_copy: bool = True, fuse_rope: bool = True):
         m, s = decoder.model, decoder.spec
+        self.flags = 0 if fuse_rope else 1          # P2T_DECODE_NO_ROPE_FUSION
         if s.hidden_size % 64:
             raise ValueError("the LM head path needs hidden_size % 64 == 0")
         self.decoder, self.spec, self.dtype = decoder, s, m.dtype
@@ -180,7 +181,7 @@ class DecodeEngine:
         layers = C.cast(st["layers"], C.POINTER(_lib.LlamaLayerStreamC)) if st else None
         head = st["lm_head"] if st else self.lm_head
         call("p2t_llama_decode_step", C.byref(self.e["cfg"]), C.byref(self.e["w"]), layers, ptr(head), self.lm_head.stride(0), int(st is not None),
-             C.byref(self.cache), ptr(self.x), ptr(self.logits), self.ld_logits, ptr(self.ws), self.ws.numel(), stream())
+             C.byref(self.cache), ptr(self.x), ptr(self.logits), self.ld_logits, self.flags, ptr(self.ws), self.ws.numel(), stream())
 
     def greedy_select(self, logits: torch.Tensor, eos: torch.Tensor, pad_id: int):
         call("p2t_greedy_select", ptr(logits), ops.dt_of(logits), logits.stride(0), self.spec.vocab_size, self.BB, ptr(eos) if eos.numel() else None,
@@ -215,7 +216,7 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
              top_k: Optional[int] = 50, top_p: Optional[float] = 1.0, num_beams: int = 1, length_penalty: float = 1.0,
              early_stopping=False, num_return_sequences: int = 1, return_dict_in_generate: bool = False, output_scores: bool = False,
              output_logits: bool = False, use_graph: bool = True, sync_every: int = 16, generator: Optional[torch.Generator] = None,
-             stream_copy: bool = True, **unused):
+             stream_copy: bool = True, fuse_rope: bool = True, **unused):
     """`LlamaForCausalLM.generate` for prompts given as embeddings (or ids): greedy, sampling (temperature / top-k / top-p) and beam
     search with length penalty.  Returns the new token ids i64 [batch * num_return_sequences, n] (or a GenerateOutput)."""
     if (inputs_embeds is None) == (input_ids is None):
@@ -255,7 +256,7 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
     if num_return_sequences != 1:
         raise NotImplementedError("num_return_sequences > 1 needs num_beams > 1")
 
-    eng = DecodeEngine(decoder, B, 1, T, max_new_tokens, stream_copy)
+    eng = DecodeEngine(decoder, B, 1, T, max_new_tokens, stream_copy, fuse_rope)
     embeds, mask = eng.compact(inputs_embeds, attention_mask)
     logits = eng.prefill(embeds, mask)
     V = decoder.spec.vocab_size

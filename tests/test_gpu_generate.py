@@ -292,13 +292,8 @@ def test_bf16_steps_vs_bf16_oracle_and_own_forward(g, case):
                            output_logits=True, stream_copy=False)
     assert torch.equal(out.sequences, out_n.sequences) and torch.equal(torch.stack(out.logits, 0), torch.stack(out_n.logits, 0))
     # ... and with the rotation + cache append as its own launch instead of the QKV GEMM's epilogue (head_dim 64 / 128): bit for bit
-    from p2t_hip import _lib
-    _lib.call("p2t_set_decode_fusion", 0)
-    try:
-        out_u = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True,
-                               output_logits=True)
-    finally:
-        _lib.call("p2t_set_decode_fusion", 1)
+    out_u = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True,
+                           output_logits=True, fuse_rope=False)
     assert torch.equal(out.sequences, out_u.sequences) and torch.equal(torch.stack(out.logits, 0), torch.stack(out_u.logits, 0))
     esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
     W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
