@@ -253,12 +253,15 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
             raise NotImplementedError("beam sampling (num_beams > 1 with do_sample=True) is not built")
         return _beam_search(decoder, inputs_embeds, attention_mask, max_new_tokens, eos_ids, int(pad_token_id), num_beams, float(length_penalty),
                             early_stopping, num_return_sequences, return_dict_in_generate, output_scores, output_logits, stream_copy)
-    if num_return_sequences != 1:
-        raise NotImplementedError("num_return_sequences > 1 needs num_beams > 1")
-
-    eng = DecodeEngine(decoder, B, 1, T, max_new_tokens, stream_copy, fuse_rope)
+    R = int(num_return_sequences)
+    if R != 1 and not do_sample:
+        raise ValueError("greedy decoding returns one sequence per prompt: num_return_sequences > 1 needs do_sample=True or num_beams > 1")
+    # R samples per prompt (HF repeats the prompt R times): R rows that SHARE the prompt segment of the cache, like the beams of a prompt
+    eng = DecodeEngine(decoder, B, R, T, max_new_tokens, stream_copy, fuse_rope)
     embeds, mask = eng.compact(inputs_embeds, attention_mask)
     logits = eng.prefill(embeds, mask)
+    if R > 1:
+        logits = logits.repeat_interleave(R, dim=0)
     V = decoder.spec.vocab_size
     eos = torch.tensor(eos_ids, dtype=torch.int64, device=eng.dev)
     keep_logits = [] if (return_dict_in_generate and (output_logits or output_scores)) else None

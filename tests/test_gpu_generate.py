@@ -324,6 +324,14 @@ def test_sampling_is_seeded_and_respects_the_filters(g):
     # top_k = 1 is greedy whatever the seed
     d = model.generate(**_inputs(g), max_new_tokens=6, eos_token_id=None, pad_token_id=meta["pad_id"], do_sample=True, top_k=1, generator=gen.manual_seed(9))
     assert np.array_equal(to_np(d), g["d64.greedy"][:, :6])
+    # several samples per prompt: rows b * R .. b * R + R - 1 share prompt b's cache segment (HF order: prompt-major)
+    r3 = model.generate(**_inputs(g), max_new_tokens=6, eos_token_id=None, pad_token_id=meta["pad_id"], do_sample=True, top_k=1, num_return_sequences=3,
+                        generator=gen.manual_seed(1))
+    assert np.array_equal(to_np(r3), np.repeat(g["d64.greedy"][:, :6], 3, axis=0))
+    s3 = model.generate(**_inputs(g), **kw, num_return_sequences=3, generator=gen.manual_seed(5))
+    assert s3.shape == (9, 6) and not torch.equal(s3[0], s3[1])
+    with pytest.raises(ValueError):
+        model.generate(**_inputs(g), max_new_tokens=2, num_return_sequences=2)
 
 
 def test_generate_refusals(g):
