@@ -153,7 +153,8 @@ torch.cuda.set_device(0)
 esm, llama, ad = _specs()
 model = build_model(esm, llama, ad, torch.float32, 3)
 B, Tp, Tt = 8, 48, 16
-tr = P.ContrastiveTrainer(model, num_segments=1 if world > 1 else 2, output_llm_layer=2, train_mode=False, lr=1e-3)
+tr = P.ContrastiveTrainer(model, num_segments=1 if world > 1 else 2, output_llm_layer=2, train_mode=False, lr=1e-3,
+                          overlap_streams=os.environ.get("P2T_TEST_OVERLAP") == "1")    # (True: towers on side streams, epoch loop pipelined)
 sl = slice(rank * (B // world), (rank + 1) * (B // world))
 batches = []
 for i in range(3):
@@ -182,26 +183,28 @@ if world > 1:
 '''
 
 
-def _run(world, tmp_path):
-    out = str(tmp_path / f"loop_w{world}_r")
+def _run(world, tmp_path, overlap=False):
+    out = str(tmp_path / f"loop_w{world}_o{int(overlap)}_r")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   P2T_TEST_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   P2T_TEST_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0", P2T_TEST_OVERLAP="1" if overlap else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
     return [json.load(open(out + str(r))) for r in range(world)]
 
 
-def test_two_ranks_epoch_on_one_gpu_equals_the_single_process_epoch(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_epoch_on_one_gpu_equals_the_single_process_epoch(tmp_path, overlap):
     """Two ranks of train_epoch / eval_epoch with the real trainer on the one GPU (gloo): rank r encodes rows [4 r, 4 r + 4) of every
     batch; the all-reduced epoch loss, the parameters after the epoch and the rank-averaged last loss equal the single-process run on
-    the whole batches with two segments; a NaN on one rank aborts the epoch on both."""
-    two, one = _run(2, tmp_path), _run(1, tmp_path)[0]
+    the whole batches with two segments; a NaN on one rank aborts the epoch on both.  overlap: the towers on side streams and the
+    epoch loop pipelined through them (next batch's towers beside this step's backward, all-reduce and optimizer)."""
+    two, one = _run(2, tmp_path, overlap), _run(1, tmp_path, overlap)[0]
     for r in two:
         assert r["batches"] == 6.0 and abs(r["train_loss"] - one["train_loss"]) < 2e-5 and abs(r["eval_loss"] - one["eval_loss"]) < 2e-5
         assert abs(r["global_last"] - one["global_last"]) < 2e-5 and r["aborted"]
