@@ -405,3 +405,29 @@ def test_fp8_gemm_model_generates_like_its_own_cacheless_forward(g, case):
     W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
     _, ref = O.generate_greedy(llama, W, to_np(emb), to_np(mask), n, (), pad, prec=O.FP8, forced=toks)
     observe(f"generate[{case}].fp8_vs_fp8oracle.logits", rel(lg, ref), 1e-1)
+
+
+@pytest.mark.parametrize("case", ["d64", "qwen3"])
+def test_long_generation_crosses_the_tile_boundaries_of_the_generated_segment(g, case):
+    """70 new tokens (the generated segment grows past its first 64-key tile, capacity 128) and a single new token: fp32 logits of every
+    step against the cache-less oracle fed the same tokens (2e-4), ids equal to the oracle's own greedy choice wherever its top-2 gap is
+    not a near-tie."""
+    model = _model(g, case, torch.float32)
+    meta = g["meta"]
+    m = meta["cases"][case]
+    n, pad = 70, meta["pad_id"]
+    out = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True,
+                         output_logits=True, sync_every=32)
+    toks, lg = to_np(out.sequences), to_np(torch.stack(out.logits, 0))
+    assert toks.shape == (3, n)
+    esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
+    W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
+    emb, mask = model(input_ids=to_dev(g["input_ids"]), attention_mask=to_dev(g["attention_mask"]), protein_input_ids=to_dev(g["protein_input_ids"]),
+                      protein_attention_mask=to_dev(g["protein_attention_mask"]), return_decoder_inputs=True)
+    _, ref = O.generate_greedy(llama, W, to_np(emb), to_np(mask), n, (), pad, forced=toks)
+    assert np.abs(lg - ref).max() < 2e-4
+    top2 = np.sort(ref, axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-3                       # [n, B]
+    assert np.array_equal(toks.T[clear], ref.argmax(-1)[clear]) and clear.mean() > 0.95
+    one = model.generate(**_inputs(g), max_new_tokens=1, eos_token_id=None, pad_token_id=pad, do_sample=False)
+    assert np.array_equal(to_np(one), toks[:, :1])
