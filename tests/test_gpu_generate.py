@@ -431,3 +431,22 @@ def test_long_generation_crosses_the_tile_boundaries_of_the_generated_segment(g,
     assert np.array_equal(toks.T[clear], ref.argmax(-1)[clear]) and clear.mean() > 0.95
     one = model.generate(**_inputs(g), max_new_tokens=1, eos_token_id=None, pad_token_id=pad, do_sample=False)
     assert np.array_equal(to_np(one), toks[:, :1])
+
+
+def test_long_beam_search_reorders_more_than_one_tile_of_generated_keys(g):
+    """3 beams x 70 new tokens: the generated cache segment that follows the beams (p2t_kv_reorder) grows past 64 keys.  fp32 ids and
+    scores against the cache-less oracle's beam search (kernels are deterministic: the comparison is stable once it holds)."""
+    case = "d64"
+    model = _model(g, case, torch.float32)
+    meta = g["meta"]
+    m = meta["cases"][case]
+    n, pad = 70, meta["pad_id"]
+    out = model.generate(**_inputs(g), max_new_tokens=n, eos_token_id=m["eos"], pad_token_id=pad, do_sample=False, num_beams=3, length_penalty=1.0,
+                         return_dict_in_generate=True, output_scores=True)
+    esm, llama, ad = specs.EsmSpec(**m["esm"]), specs.LlamaSpec(**m["llama"]), specs.AdapterSpec(**m["adapter"])
+    W = model_weights(esm, llama, ad, m["weight_seed"], lm_head=True)
+    emb, mask = model(input_ids=to_dev(g["input_ids"]), attention_mask=to_dev(g["attention_mask"]), protein_input_ids=to_dev(g["protein_input_ids"]),
+                      protein_attention_mask=to_dev(g["protein_attention_mask"]), return_decoder_inputs=True)
+    seq, sc = O.generate_beam(llama, W, to_np(emb), to_np(mask), n, 3, (m["eos"],), pad, 1.0)
+    assert np.array_equal(to_np(out.sequences), seq) and seq.shape[1] > 64
+    assert np.abs(to_np(out.sequences_scores) - sc).max() < 1e-4
