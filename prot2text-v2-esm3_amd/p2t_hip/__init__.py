@@ -23,7 +23,7 @@ __all__ = ["specs", "synth", "Esm2LlamaInstructConfig", "ModalityAdapterConfig",
            "get_description_embeddings", "teacher_forcing_forward_pass", "ContrastiveTrainer", "ops",
            "EsmSequenceTokenizer", "ContrastiveCollater", "DevicePrefetcher", "sort_batch_by_length", "CosineWarmupSchedule", "save_checkpoint",
            "load_model_checkpoint", "load_optimizer_scheduler_checkpoint", "train_epoch", "eval_epoch", "run_epochs",
-           "iterative_generation_loop", "inference_epoch"]
+           "iterative_generation_loop", "inference_epoch", "load_and_merge_adapter"]
 
 _LAZY = {
     "Esm2LlamaInstructConfig": "configuration", "ModalityAdapterConfig": "configuration",
@@ -35,7 +35,7 @@ _LAZY = {
     "EsmSequenceTokenizer": "data", "ContrastiveCollater": "data", "DevicePrefetcher": "data", "sort_batch_by_length": "data",
     "CosineWarmupSchedule": "training_state", "save_checkpoint": "training_state",
     "load_model_checkpoint": "training_state", "load_optimizer_scheduler_checkpoint": "training_state",
-    "train_epoch": "loop", "eval_epoch": "loop", "run_epochs": "loop", "iterative_generation_loop": "loop", "inference_epoch": "loop",
+    "train_epoch": "loop", "eval_epoch": "loop", "run_epochs": "loop", "iterative_generation_loop": "loop", "inference_epoch": "loop", "load_and_merge_adapter": "lora",
 }
 
 
