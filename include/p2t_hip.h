@@ -183,7 +183,10 @@ int p2t_qkv_post(const void* qkv, int64_t ldq, const float* inv_freq, float* cos
  * next multiple of 64 (the o-proj K padding) zeroed.  causal: also require key <= query.
  * log2_scores != 0: q was stored pre-multiplied by scale * log2(e) (what the towers do for bf16 models, through the q_scale
  * of p2t_gemm_qkv_rope / p2t_qkv_post: q is rounded to bf16 once either way), so q k^T is the base-2 exponent itself:
- * `scale` is ignored, the result is softmax_2(q k^T + mask) v = the same attention, one multiply-add less per score. */
+ * `scale` is ignored, the result is softmax_2(q k^T + mask) v = the same attention, one multiply-add less per score.
+ * use_mfma: -1 auto / 1 require = the MFMA kernels (bf16): the hand-placed kernel (csrc/attn_fwd64.hip) where dp == 64,
+ * d % 8 == 0 and log2_scores, else the general one (csrc/attn_mfma.hip); 2 = the general MFMA kernel everywhere;
+ * 3 = require the hand-placed one; 0 = the exact fp32-softmax kernel. */
 int p2t_attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info,
                   void* out, int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal,
                   int dtype, int use_mfma, int log2_scores, float* lse, p2t_stream stream);

@@ -1,0 +1,181 @@
+// bf16 flash attention forward for gfx950, head_dim padded to 64 (ESM2-3B: 40 heads x 64; Llama-3.2-1B: 32 / 8 heads x 64):
+// the hand-placed form.  Same semantics as attn_mfma.hip (log2-scores q, key-padding / causal / GQA, optional log-sum-exp).
+//
+// One workgroup = 4 wavefronts = 256 queries of one (batch, head), ONE wave per SIMD with the whole 512-register file; a wave
+// owns two 32-query tiles (A, B).  Per 64-key tile j the wave runs two segments of 16 MFMAs (v_mfma_f32_32x32x16_bf16): the
+// softmax of one query tile (exp2 / row sum / bf16 pack, the next tile's row maximum) is issued on the vector pipe in the gaps
+// of the OTHER tile's QK^T and PV MFMAs, so neither pipe waits for the other inside a wave (attn_mfma.hip leaves that overlap
+// to three co-resident waves and the compiler's order: 0.30 of the MFMA peak, issue-bound).  K / V fragments
+// live in AGPRs, double-buffered by tile parity, so both query tiles share every LDS fragment read; the K / V tiles arrive by
+// LDS-DMA into two 4-slot rings (K five tiles ahead, V three), one barrier per tile with a counted vmcnt.
+//
+// The loop is one asm statement with literal registers, written by tools/gen_attn_fwd64.py (segment anatomy, register map and
+// the rare paths -- reference rescale, hidden keys -- are documented there); this file sets up its pinned inputs and runs the
+// epilogue (normalise, stage O through LDS, whole-row stores).
+#include "common.h"
+#include "kernels.h"
+
+#include "attn_fwd64_body.inc"
+
+namespace p2t {
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kA64Slot = 8192, kA64Slots = 4;
+constexpr int kA64Ring = 2 * kA64Slots * kA64Slot;           // K ring + V ring
+constexpr int kA64Lds = kA64Ring + 4 * 8192;                 // + one 64-query x 128-B output stage per wave
+
+__device__ __forceinline__ int a64_perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+__device__ __forceinline__ int a64_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                             const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                             const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out, int64_t ld_out,
+                                                             int B, int seq, int nh, int nkv, int d, int out_cols, float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) char smem[kA64Lds];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware block order (attn_mfma.hip): the query blocks of one (batch, head) share an L2
+    const int n_qb = (seq + 255) >> 8, n_hb = nh * B, hb_full = n_hb & ~7;
+    const int id = blockIdx.x;
+    int qb, hb;
+    if (id < hb_full * n_qb) {
+        const int slot = id >> 3;
+        hb = (slot / n_qb) * 8 + (id & 7);
+        qb = slot % n_qb;
+    } else {
+        const int rid = id - hb_full * n_qb;
+        hb = hb_full + rid / n_qb;
+        qb = rid % n_qb;
+    }
+    const int h = hb % nh, b = hb / nh;
+    const int hk = h / (nh / nkv);
+    const int q0 = qb * 256 + w * 64;
+    const int lq = lane & 31, hh = lane >> 5;
+
+    int end = kv_info[b];
+    const int prefix = kv_info[B + b];
+    if (CAUSAL) end = min(end, qb * 256 + 256);
+    end = min(end, seq);
+    const int n_it = (end + 63) >> 6;
+
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // fragment read addresses (slot 0): K row pi(lq) (+ 32 per tile half), 16-byte chunk (2 kk + hh) ^ g(row)
+    i32x4 ka, va, voffs, misc;
+    {
+        const int row = a64_perm23(lq);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ka[kk] = (int)(lds0 + row * 128 + (((kk * 2 + hh) ^ a64_swz(row)) << 4));
+        // V^T operand: 16-lane group (lane >> 4) reads the 4 x 16 block rows 8 hh + 4 r + qq (+ 16 per key step), columns
+        // dt * 32 + 16 g1 + 4 pp .. +3  (ds_read_b64_tr_b16)
+        const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int vrow = 8 * hh + 4 * r + qq, col = dt * 32 + 16 * g1 + 4 * pp;
+                va[dt * 2 + r] = (int)(lds0 + kA64Slots * kA64Slot + vrow * 128 + (((col >> 3) ^ a64_swz(vrow)) << 4) + (col & 7) * 2);
+            }
+        // DMA source offsets of this wave's two 1-KiB pieces (rows 8 (w + 4 i) .. + 7 of a tile; the LDS image is lane-linear,
+        // so the swizzle is applied to the source address), and the same with rows past the sequence end re-reading its last row
+        const int tail0 = (seq >> 6) << 6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int byte = (w + 4 * i) * 1024 + lane * 16;
+            const int row = byte >> 7, p = (byte & 127) >> 4;
+            const int chunk = (p ^ a64_swz(row)) << 4;
+            voffs[i] = row * 128 + chunk;
+            voffs[2 + i] = min(row, max(seq - 1 - tail0, 0)) * 128 + chunk;
+        }
+        const int qa = min(q0 + lq, seq - 1), qbq = min(q0 + 32 + lq, seq - 1);
+        misc[0] = qa * 128 + 16 * hh;
+        misc[1] = qbq * 128 + 16 * hh;
+        misc[2] = q0 + lq + 1 - 8 * hh;
+        misc[3] = q0 + 32 + lq + 1 - 8 * hh;
+    }
+    i32x2 lanes = {8 * hh, lane};
+    uint64_t kptr = (uint64_t)(k + ((int64_t)(b * nkv + hk) * seq) * 64);
+    uint64_t vptr = (uint64_t)(v + ((int64_t)(b * nkv + hk) * seq) * 64);
+    const uint64_t qptr = (uint64_t)(q + ((int64_t)(b * nh + h) * seq) * 64);
+    const uint64_t mptr = (uint64_t)(key_mask + (int64_t)b * seq);
+    const int s_nit = n_it, s_ldsk = (int)(lds0 + w * 1024), s_seq = seq, s_flags = ((end & 63) != 0 ? 1 : 0) | (prefix ? 0 : 2);
+    const int q0s = q0;
+
+    f32x16 oA0, oA1, oB0, oB1;
+    f32x4 lsum;
+    f32x2 mref;
+    if constexpr (CAUSAL)
+        asm volatile(P2T_ATTN64_BODY_1
+                     : "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={v[128:131]}"(lsum), "={v[132:133]}"(mref),
+                       "+{s[36:37]}"(kptr), "+{s[38:39]}"(vptr)
+                     : "{s[40:41]}"(qptr), "{s[42:43]}"(mptr), "{s44}"(s_nit), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(s_flags), "{s49}"(q0s), "{v[138:141]}"(ka), "{v[142:145]}"(va),
+                       "{v[150:153]}"(voffs), "{v[154:157]}"(misc), "{v[158:159]}"(lanes)
+                     : P2T_ATTN64_CLOBBERS);
+    else
+        asm volatile(P2T_ATTN64_BODY_0
+                     : "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={v[128:131]}"(lsum), "={v[132:133]}"(mref),
+                       "+{s[36:37]}"(kptr), "+{s[38:39]}"(vptr)
+                     : "{s[40:41]}"(qptr), "{s[42:43]}"(mptr), "{s44}"(s_nit), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(s_flags), "{s49}"(q0s), "{v[138:141]}"(ka), "{v[142:145]}"(va),
+                       "{v[150:153]}"(voffs), "{v[154:157]}"(misc), "{v[158:159]}"(lanes)
+                     : P2T_ATTN64_CLOBBERS);
+
+    // ---- epilogue: O^T rows = channels (r & 3) + 8 (r >> 2) + 4 hh (+ 32 per d-tile), column = query ----
+    char* stage = smem + kA64Ring + w * 8192;                 // [64 queries][128 B], 16-byte chunk c of row r at c ^ (r & 7)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        float l = x == 0 ? lsum[0] + lsum[1] : lsum[2] + lsum[3];
+        l += __shfl_xor(l, 32, 64);
+        const float m = mref[x];
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int query = q0 + 32 * x + lq;
+        if (lse && hh == 0 && query < seq) lse[(int64_t)(b * nh + h) * seq + query] = l > 0.f ? kLn2 * (m + __log2f(l)) : INFINITY;
+        const int row = 32 * x + lq;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const f32x16& o = x == 0 ? (dt == 0 ? oA0 : oA1) : (dt == 0 ? oB0 : oB1);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c16 = dt * 4 + rg;
+                *reinterpret_cast<uint2*>(stage + row * 128 + ((c16 ^ (row & 7)) << 4) + 8 * hh) =
+                    make_uint2(pack_bf16x2(o[4 * rg] * inv, o[4 * rg + 1] * inv), pack_bf16x2(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv));
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the stage is private to the wave: program order + this wait is enough
+    const int c = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + (lane >> 3), query = q0 + row;
+        const uint4 val = *reinterpret_cast<const uint4*>(stage + row * 128 + ((c ^ (row & 7)) << 4));
+        if (query < seq) {
+            bf16_t* orow = out + ((int64_t)b * seq + query) * ld_out;
+            if (c * 8 < d) *reinterpret_cast<uint4*>(orow + h * d + c * 8) = val;
+            if (h == nh - 1)
+                for (int cc = nh * d + c * 8; cc < out_cols; cc += 64) *reinterpret_cast<uint4*>(orow + cc) = make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+bool attn_fwd64_eligible(int64_t ld_out, int T, int nh, int nkv, int d, int dp, int log2_scores) {
+    return dp == 64 && log2_scores && d % 8 == 0 && d <= 64 && nh % nkv == 0 && ld_out % 8 == 0 && (nh * d) % 8 == 0 && T >= 1;
+}
+
+int launch_attn_fwd64(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out, int64_t ld_out,
+                      int B, int T, int nh, int nkv, int d, int causal, float* lse, hipStream_t s) {
+    P2T_REQUIRE(attn_fwd64_eligible(ld_out, T, nh, nkv, d, 64, 1), "attention(fwd64): unsupported shape d=%d heads %d/%d", d, nh, nkv);
+    const dim3 grid((unsigned)(ceil_div(T, 256) * nh * B));
+    const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
+    if (causal)
+        attn_fwd64_kernel<true><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, (bf16_t*)out, ld_out,
+                                                     B, T, nh, nkv, d, out_cols, lse);
+    else
+        attn_fwd64_kernel<false><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, (bf16_t*)out, ld_out,
+                                                      B, T, nh, nkv, d, out_cols, lse);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+}  // namespace p2t

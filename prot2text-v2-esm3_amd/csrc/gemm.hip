@@ -121,11 +121,18 @@ int attention(const void* q, const void* k, const void* v, const uint8_t* key_ma
     P2T_REQUIRE(ld_out >= (int64_t)nh * d, "attention: ld_out too small");
     if (dtype == P2T_BF16 && use_mfma != 0) {
         const int pi = prof_begin(s, 1, 4.0 * B * nh * (double)T * T * d * (causal ? 0.5 : 1.0));
-        const int rc = launch_attn_mfma(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, log2_scores, lse, s);
+        // use_mfma: 2 = the general kernel (attn_mfma.hip) even where the hand-placed one applies; 3 = require the hand-placed one
+        const bool hand = use_mfma != 2 && attn_fwd64_eligible(ld_out, T, nh, nkv, d, dp, log2_scores);
+        if (use_mfma == 3 && !hand) {
+            set_error("attention: the hand-placed kernel needs head_dim padded to 64, d %% 8 == 0 and log2_scores (d=%d dp=%d)", d, dp);
+            return P2T_ERR_UNSUPPORTED;
+        }
+        const int rc = hand ? launch_attn_fwd64(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, causal, lse, s)
+                            : launch_attn_mfma(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, scale, causal, log2_scores, lse, s);
         prof_end(s, pi);
         return rc;
     }
-    P2T_REQUIRE(use_mfma != 1, "attention: MFMA kernel needs bf16");
+    P2T_REQUIRE(use_mfma <= 0, "attention: MFMA kernel needs bf16");
     // exp(ln 2 * (s - m)) = 2^(s - m)
     return launch_attn_simple(q, k, v, key_mask, kv_info, out, ld_out, B, T, nh, nkv, d, dp, log2_scores ? kLn2 : scale, causal, dtype, lse, s);
 }

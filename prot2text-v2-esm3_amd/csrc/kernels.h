@@ -99,6 +99,10 @@ int launch_attn_simple(const void* q, const void* k, const void* v, const uint8_
                        float* lse, hipStream_t s);
 int launch_attn_mfma(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
                      int64_t ld_out, int B, int T, int nh, int nkv, int d, int dp, float scale, int causal, int log2_scores, float* lse, hipStream_t s);
+// hand-placed form for head_dim padded to 64 with log2-scores q (attn_fwd64.hip; tools/gen_attn_fwd64.py writes its loop)
+bool attn_fwd64_eligible(int64_t ld_out, int T, int nh, int nkv, int d, int dp, int log2_scores);
+int launch_attn_fwd64(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out, int64_t ld_out,
+                      int B, int T, int nh, int nkv, int d, int causal, float* lse, hipStream_t s);
 // log2_scores: q was stored pre-multiplied by scale * log2(e) (kLog2e below), so q k^T is already the base-2 exponent: `scale` is
 // ignored and p = exp2(s - m).  The towers do this for bf16 models (one multiply + add less per score in the MFMA kernel).
 int attention(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out,
