@@ -30,17 +30,21 @@ constexpr int kA64Lds = kA64Ring + 4 * 8192;                 // + one 64-query x
 __device__ __forceinline__ int a64_perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ int a64_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-template <bool CAUSAL>
+template <bool CAUSAL, int DIAG = 0>
 __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                              const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
                                                              const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out, int64_t ld_out,
-                                                             int B, int seq, int nh, int nkv, int d, int out_cols, float* __restrict__ lse) {
+                                                             int B, int seq, int nh, int nkv, int d, int out_cols, float* lse, int n_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[kA64Lds];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware block order (attn_mfma.hip): the query blocks of one (batch, head) share an L2
+    // Persistent: one workgroup per CU walks the query blocks id = blockIdx.x, + gridDim.x, ... (a new workgroup of this size
+    // starts 2.2 us after its predecessor ends -- 9 % of the launch at ten blocks per CU, profiles/r04_attn64_v3_gaps.log).
+    // XCD-aware block order (attn_mfma.hip): the query blocks of one (batch, head) share an L2; gridDim.x is a multiple of 8,
+    // so a workgroup's blocks stay on its XCD's residue.
     const int n_qb = (seq + 255) >> 8, n_hb = nh * B, hb_full = n_hb & ~7;
-    const int id = blockIdx.x;
+    for (int id = blockIdx.x; id < n_blocks; id += gridDim.x) {
+    if (id != (int)blockIdx.x) __builtin_amdgcn_s_barrier();      // every wave is done with the previous block's K / V ring
     int qb, hb;
     if (id < hb_full * n_qb) {
         const int slot = id >> 3;
@@ -105,33 +109,57 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
     const int q0s = q0;
 
     f32x16 oA0, oA1, oB0, oB1;
-    f32x4 lsum;
+    float lA, lB;                 // row sums (the ones-row of the PV product: every lane holds its query's whole sum)
     f32x2 mref;
+#define P2T_ATTN64_OUTS "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={a224}"(lA), "={a240}"(lB), "={v[132:133]}"(mref), \
+                        "+{s[36:37]}"(kptr), "+{s[38:39]}"(vptr)
+#define P2T_ATTN64_INS "{s[40:41]}"(qptr), "{s[42:43]}"(mptr), "{s44}"(s_nit), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(s_flags), "{s49}"(q0s), \
+                       "{v[138:141]}"(ka), "{v[142:145]}"(va), "{v[150:153]}"(voffs), "{v[154:157]}"(misc), "{v[158:159]}"(lanes)
+#ifdef P2T_LAB
+    if constexpr (DIAG != 0) {
+        // diagnostic build: cycles per phase of this wave (tools/gen_attn_fwd64.py, stamp()), written where the log-sum-exps would go
+        const long long t_in = __builtin_amdgcn_s_memtime();
+        const long long r_in = __builtin_amdgcn_s_memrealtime();
+        unsigned c0, c1, c2, c3, c4, c5, c6, c7;
+#define P2T_ATTN64_DIAG(N)                                                                                                                    \
+        if constexpr (DIAG == N)                                                                                                                  \
+            asm volatile(P2T_ATTN64_BODY_DIAG##N                                                                                                 \
+                         : P2T_ATTN64_OUTS, "={s70}"(c0), "={s71}"(c1), "={s72}"(c2), "={s73}"(c3), "={s74}"(c4), "={s75}"(c5), "={s76}"(c6), "={s77}"(c7) \
+                         : P2T_ATTN64_INS                                                                                                        \
+                         : P2T_ATTN64_CLOBBERS_DIAG);
+        P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8)
+#undef P2T_ATTN64_DIAG
+        if (lane == 0) {
+            float* dst = lse + ((int64_t)id * 4 + w) * 16;
+            const unsigned c[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+            for (int i = 0; i < 8; ++i) dst[i] = (float)c[i];
+            dst[8] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_in);
+            dst[9] = (float)n_it;
+            // wall clock (100 MHz) at entry / exit and where the block ran: the gaps between the blocks of one CU and the clock it held
+            const long long r_out = __builtin_amdgcn_s_memrealtime();
+            dst[10] = (float)(unsigned)(r_in & 0xFFFFFF);
+            dst[11] = (float)(unsigned)(r_out & 0xFFFFFF);
+            dst[12] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);          // HW_ID (wave / simd / cu / sh / se ...)
+            dst[13] = (float)__builtin_amdgcn_s_getreg((31 << 11) | 20);                      // XCC_ID
+        }
+    } else
+#endif
     if constexpr (CAUSAL)
-        asm volatile(P2T_ATTN64_BODY_1
-                     : "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={v[128:131]}"(lsum), "={v[132:133]}"(mref),
-                       "+{s[36:37]}"(kptr), "+{s[38:39]}"(vptr)
-                     : "{s[40:41]}"(qptr), "{s[42:43]}"(mptr), "{s44}"(s_nit), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(s_flags), "{s49}"(q0s), "{v[138:141]}"(ka), "{v[142:145]}"(va),
-                       "{v[150:153]}"(voffs), "{v[154:157]}"(misc), "{v[158:159]}"(lanes)
-                     : P2T_ATTN64_CLOBBERS);
+        asm volatile(P2T_ATTN64_BODY_1 : P2T_ATTN64_OUTS : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS);
     else
-        asm volatile(P2T_ATTN64_BODY_0
-                     : "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={v[128:131]}"(lsum), "={v[132:133]}"(mref),
-                       "+{s[36:37]}"(kptr), "+{s[38:39]}"(vptr)
-                     : "{s[40:41]}"(qptr), "{s[42:43]}"(mptr), "{s44}"(s_nit), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(s_flags), "{s49}"(q0s), "{v[138:141]}"(ka), "{v[142:145]}"(va),
-                       "{v[150:153]}"(voffs), "{v[154:157]}"(misc), "{v[158:159]}"(lanes)
-                     : P2T_ATTN64_CLOBBERS);
+        asm volatile(P2T_ATTN64_BODY_0 : P2T_ATTN64_OUTS : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS);
+#undef P2T_ATTN64_OUTS
+#undef P2T_ATTN64_INS
 
     // ---- epilogue: O^T rows = channels (r & 3) + 8 (r >> 2) + 4 hh (+ 32 per d-tile), column = query ----
     char* stage = smem + kA64Ring + w * 8192;                 // [64 queries][128 B], 16-byte chunk c of row r at c ^ (r & 7)
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-        float l = x == 0 ? lsum[0] + lsum[1] : lsum[2] + lsum[3];
-        l += __shfl_xor(l, 32, 64);
+        const float l = x == 0 ? lA : lB;
         const float m = mref[x];
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int query = q0 + 32 * x + lq;
-        if (lse && hh == 0 && query < seq) lse[(int64_t)(b * nh + h) * seq + query] = l > 0.f ? kLn2 * (m + __log2f(l)) : INFINITY;
+        if (DIAG == 0 && lse && hh == 0 && query < seq) lse[(int64_t)(b * nh + h) * seq + query] = l > 0.f ? kLn2 * (m + __log2f(l)) : INFINITY;
         const int row = 32 * x + lq;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -157,6 +185,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
                 for (int cc = nh * d + c * 8; cc < out_cols; cc += 64) *reinterpret_cast<uint4*>(orow + cc) = make_uint4(0, 0, 0, 0);
         }
     }
+    }       // persistent loop
 }
 
 bool attn_fwd64_eligible(int64_t ld_out, int T, int nh, int nkv, int d, int dp, int log2_scores) {
@@ -166,14 +195,33 @@ bool attn_fwd64_eligible(int64_t ld_out, int T, int nh, int nkv, int d, int dp, 
 int launch_attn_fwd64(const void* q, const void* k, const void* v, const uint8_t* key_mask, const int32_t* kv_info, void* out, int64_t ld_out,
                       int B, int T, int nh, int nkv, int d, int causal, float* lse, hipStream_t s) {
     P2T_REQUIRE(attn_fwd64_eligible(ld_out, T, nh, nkv, d, 64, 1), "attention(fwd64): unsupported shape d=%d heads %d/%d", d, nh, nkv);
-    const dim3 grid((unsigned)(ceil_div(T, 256) * nh * B));
+    const int n_blocks = (int)(ceil_div(T, 256) * nh * B);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n & ~7 ? n & ~7 : 8;
+    }
+    const dim3 grid((unsigned)(n_blocks < cus ? n_blocks : cus));
     const int out_cols = (int)(round_up((int64_t)nh * d, 64) < ld_out ? round_up((int64_t)nh * d, 64) : ld_out);
+#ifdef P2T_LAB
+    if (causal >= 2) {          // lab build: stamped kernels (non-causal), variant causal - 1; lse = the stamp buffer, f32 [grid * 4 waves * 16]
+#define P2T_ATTN64_DIAG(N)                                                                                                                     \
+        if (causal - 1 == N)                                                                                                                   \
+            attn_fwd64_kernel<false, N><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, (bf16_t*)out, \
+                                                             ld_out, B, T, nh, nkv, d, out_cols, lse, n_blocks);
+        P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8)
+#undef P2T_ATTN64_DIAG
+        P2T_LAUNCH_CHECK();
+        return P2T_OK;
+    }
+#endif
     if (causal)
         attn_fwd64_kernel<true><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, (bf16_t*)out, ld_out,
-                                                     B, T, nh, nkv, d, out_cols, lse);
+                                                     B, T, nh, nkv, d, out_cols, lse, n_blocks);
     else
         attn_fwd64_kernel<false><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, (bf16_t*)out, ld_out,
-                                                      B, T, nh, nkv, d, out_cols, lse);
+                                                      B, T, nh, nkv, d, out_cols, lse, n_blocks);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }

@@ -4,19 +4,23 @@ head_dim padded to 64, one wave per SIMD, two 32-query tiles per wave).
 
 The whole K/V loop is ONE asm statement with literal registers; hipcc only sets up its pinned inputs and runs the epilogue.
 Why literal registers: an inline-asm operand cannot name ONE register of a tuple, and the softmax works on single registers
-of the 16-register MFMA results (tools/README.md, "attention forward").
+of the 16-register MFMA results.
 
 Per wave: tile A = queries q0 .. q0+31, tile B = q0+32 .. q0+63.  Iteration j (key tile j, 64 keys) is two segments of
-16 MFMAs each; the softmax of one tile runs on the vector pipe under the other tile's MFMAs:
+20 MFMAs each; the softmax of one tile runs on the vector pipe under the other tile's MFMAs:
 
-    segment 1:  MFMA  QK_B(j)  [8]  PV_B(j-1) [8]      VALU  exp / sum / bf16-pack of S_A(j), row max of S_B(j)
-                LDS   V(j) fragments (16 transposed reads)      DMA  V(j+3)
-    segment 2:  MFMA  QK_A(j+1)[8]  PV_A(j)   [8]      VALU  exp / sum / bf16-pack of S_B(j), row max of S_A(j+1)
-                LDS   K(j+2) fragments (8 reads)                DMA  K(j+5)
+    segment 1:  MFMA  QK_B(j)  [8]  PV_B(j-1) + row sums [8 + 4]   VALU  exp / bf16-pack of S_A(j), row max of S_B(j)
+                LDS   V(j) fragments (16 transposed reads)          DMA  V(j+3)
+    segment 2:  MFMA  QK_A(j+1)[8]  PV_A(j)   + row sums [8 + 4]   VALU  exp / bf16-pack of S_B(j), row max of S_A(j+1)
+                LDS   K(j+2) fragments (8 reads)                    DMA  K(j+5)
 
-K and V fragments are double-buffered in AGPRs (set = tile & 1) so both query tiles use one LDS read of them.
-Rare paths (not hand-placed): the rescale of the running maximum (a score more than 2^8 above it, the first tile, or a
-mask that is not a prefix) and the masking of a tile that holds a hidden key.
+The row sums of P are a fifth "d-tile" of the PV product: an all-ones A operand against the same packed P (4 MFMAs per
+segment on the matrix pipe, which has the slack, instead of 32 v_add_f32 on the vector pipe, which is the longer one:
+profiles/r04_attn64_v1_diag.log).  K and V fragments are double-buffered in AGPRs (set = tile & 1) so both query tiles use
+one LDS read of them; the loop is unrolled over the 4 ring slots so every LDS address is a register + immediate.
+Rare paths (out of line, entered through s_setpc stubs): the rescale of the running maximum (a score more than 2^8 above
+it, the first tile, or a mask that is not a prefix), the masking of a tile that holds a hidden key, and the switch of the
+DMA source offsets to the clamped ones for the tile that crosses the end of the sequence.
 
     python tools/gen_attn_fwd64.py            # rewrite the .inc in place
 """
@@ -27,35 +31,34 @@ OUT = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc", "attn_fwd64_body.inc")
 
 NS = 4                      # LDS ring slots per operand (K and V each); a slot = 64 keys x 128 B = 8 KiB
 SLOT = 8192
-SLACK = "0x41000000"        # 8.0: lazy-rescale threshold, log2 units
 NINF = "0xff800000"
+ONES = "0x3f803f80"         # two bf16 1.0
 
 # ---- register map (must match attn_fwd64.hip) -------------------------------------------------
 S = {"A": 0, "B": 32}                   # v: scores / probabilities, 32 per tile (t0: +0..15, t1: +16..31)
 P = {"A": 64, "B": 80}                  # v: packed bf16 probabilities, 16 per tile
 NEGM = {"A": 96, "B": 112}              # v: -m on 16 registers (accumulator input of QK^T)
-LSUM = {"A": (128, 129), "B": (130, 131)}
 MREF = {"A": 132, "B": 133}
 SEEN = {"A": 134, "B": 135}
 MLOC = {"A": 136, "B": 137}
 KA = 138                                # v138..141: K fragment read address per k-step (slot 0)
 VA = 142                                # v142..145: V transposed-read address per (dt, r)
-CKA = 146                               # v146..149: the same for the slot being read this iteration
-VOFF = 150                              # v150,151 DMA source offsets of this wave's two pieces; v152,153 the clamped ones of the tail tile
+DVK, DVV = 146, 148                     # v146,147 / v148,149: DMA source offsets in use for K / V (switched to the clamped ones at the tail tile)
+VOFF = 150                              # v150,151 offsets of this wave's two pieces; v152,153 the clamped ones of the tail tile
 QOFF = {"A": 154, "B": 155}
 CQ = {"A": 156, "B": 157}               # query + 1 - 8 hh (causal limit in the shifted key coordinates)
 HH8 = 158
 LANE = 159
-CVA = 160                               # v160..163
-DV = 164                                # DMA offset temporary
 T = [166 + i for i in range(8)]         # temporaries of the rare paths
 W = (174, 175)
 LM = (176, 177)
 NINFV = 178
-MAXV = 179                              # highest VGPR the asm owns; the compiler keeps v[200:255]
+ONEV = 180                              # v180..183: all-ones bf16 fragment (A operand of the row-sum MFMAs)
+MAXV = 183                              # highest VGPR the asm owns
 
 O = {"A": (0, 16), "B": (32, 48)}       # a: O^T accumulators per d-tile
 Q = {"A": 64, "B": 80}                  # a: + 4 kk
+LACC = {"A": 224, "B": 240}             # a: row-sum accumulators (every register of a lane holds its query's sum)
 
 
 def KF(st, t, kk):
@@ -66,18 +69,22 @@ def VF(st, dt, ss):
     return 160 + st * 32 + (dt * 4 + ss) * 4
 
 
-MAXA = 223
-
 # SGPRs
 KPTR, VPTR, QPTR, MPTR = 36, 38, 40, 42         # pairs
 NIT, LDSK, SEQ, FLAGS = 44, 45, 46, 47          # FLAGS: bit0 = last tile partial, bit1 = mask is not a prefix
 LDSV, Q0, TAILT, NITM1 = 48, 49, 50, 51
-J, R, TK, TV, SL, SL1, SL2, SL3, DST, TMP, TMP2, KB, MF = 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64
-VIS, CC = 66, 68                                # pairs
-MAXS = 69
+J, R, TK, TV, J1, SLK, SLKS, MFROM, TMP, TMP2, KB = 52, 53, 54, 55, 56, 57, 58, 59, 61, 62, 63
+VIS, CC, RET = 66, 68, 84                       # pairs
+ACC0, PREV, CUR = 70, 78, 80                    # diagnostic build: s70..77 cycle sums per phase, s78 previous stamp, s[80:81] s_memtime
+MAXS = 85
+
+# knobs of the diagnostic variants (lab build): the product uses the defaults
+VAR = {"dma_gaps": (5, 15), "no_dma": False, "no_softmax": False, "no_lds": False, "no_exp": False, "no_cvtmax": False, "qk_agpr": False}
 
 L = []
+TAIL = []                   # out-of-line code, emitted after the main stream
 _lab = [0]
+DIAG = [False]
 
 
 def e(s):
@@ -101,18 +108,50 @@ def sr(b, n=1):
     return f"s{b}" if n == 1 else f"s[{b}:{b + n - 1}]"
 
 
+def stamp(k):
+    """Diagnostic build only: add the cycles since the previous stamp to phase k (s_memtime returns through lgkmcnt)."""
+    if not DIAG[0]:
+        return
+    e(f"s_memtime {sr(CUR, 2)}")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_sub_u32 {sr(TMP)}, {sr(CUR)}, {sr(PREV)}")
+    e(f"s_add_u32 {sr(ACC0 + k)}, {sr(ACC0 + k)}, {sr(TMP)}")
+    e(f"s_mov_b32 {sr(PREV)}, {sr(CUR)}")
+
+
+def call(cond_branch, sub, pre=()):
+    """Hot path: `cond_branch stub`; the stub (out of line) loads the return address and jumps to the subroutine `sub`, which
+    ends with s_setpc_b64 RET."""
+    stub, back, pc = lab("stub"), lab("back"), lab("pc")
+    e(f"{cond_branch} {stub}")
+    e(f"{back}:")
+    TAIL.append(f"{stub}:")
+    TAIL.extend(pre)
+    TAIL.append(f"s_getpc_b64 {sr(RET, 2)}")
+    TAIL.append(f"{pc}:")
+    TAIL.append(f"s_sub_u32 {sr(RET)}, {sr(RET)}, {pc} - {back}")
+    TAIL.append(f"s_subb_u32 {sr(RET + 1)}, {sr(RET + 1)}, 0")
+    TAIL.append(f"s_branch {sub}")
+
+
 # ---- building blocks ---------------------------------------------------------------------------
 def mfma_qk(Y, kset, i):
     t, kk = i >> 2, i & 3
     d = S[Y] + 16 * t
     c = vr(NEGM[Y], 16) if kk == 0 else vr(d, 16)
+    if VAR["qk_agpr"]:          # timing experiment only: the scores land in the O accumulators
+        return f"v_mfma_f32_32x32x16_bf16 {ar(d, 16)}, {ar(KF(kset, t, kk), 4)}, {ar(Q[Y] + 4 * kk, 4)}, {ar(d, 16)}"
     return f"v_mfma_f32_32x32x16_bf16 {vr(d, 16)}, {ar(KF(kset, t, kk), 4)}, {ar(Q[Y] + 4 * kk, 4)}, {c}"
 
 
 def mfma_pv(Y, vset, i):
-    ss, dt = i >> 1, i & 1
-    o = O[Y][dt]
-    return f"v_mfma_f32_32x32x16_bf16 {ar(o, 16)}, {ar(VF(vset, dt, ss), 4)}, {vr(P[Y] + 4 * ss, 4)}, {ar(o, 16)}"
+    """12 MFMAs: per 16-key step ss the two d-tiles of O^T and the row sums."""
+    ss, k = divmod(i, 3)
+    if k == 2:
+        o = LACC[Y]
+        return f"v_mfma_f32_32x32x16_bf16 {ar(o, 16)}, {vr(ONEV, 4)}, {vr(P[Y] + 4 * ss, 4)}, {ar(o, 16)}"
+    o = O[Y][k]
+    return f"v_mfma_f32_32x32x16_bf16 {ar(o, 16)}, {ar(VF(vset, k, ss), 4)}, {vr(P[Y] + 4 * ss, 4)}, {ar(o, 16)}"
 
 
 def max_chain(Y):
@@ -128,248 +167,324 @@ def max_chain(Y):
     return out
 
 
-def dma_piece(tile_s, dst_s, ptr_s, piece):
-    """One 1-KiB LDS-DMA piece of tile `tile_s` (skipped past the last tile; the tail tile re-reads its last row)."""
-    skip = lab("nodma")
-    return [
-        f"s_cmp_lt_u32 {sr(tile_s)}, {sr(NIT)}",
-        f"s_cbranch_scc0 {skip}",
-        f"s_cmp_eq_u32 {sr(tile_s)}, {sr(TAILT)}",
-        f"s_cselect_b64 {sr(CC, 2)}, -1, 0",
-        f"s_add_u32 {sr(TMP)}, {sr(dst_s)}, {piece * 4096}",
-        f"s_mov_b32 m0, {sr(TMP)}",
-        f"v_cndmask_b32 {vr(DV)}, {vr(VOFF + piece)}, {vr(VOFF + 2 + piece)}, {sr(CC, 2)}",
-        f"global_load_lds_dwordx4 {vr(DV)}, {sr(ptr_s, 2)}",
-        f"{skip}:",
-    ]
-
-
-def advance(ptr_s):
-    return [f"s_add_u32 {sr(ptr_s)}, {sr(ptr_s)}, {SLOT}", f"s_addc_u32 {sr(ptr_s + 1)}, {sr(ptr_s + 1)}, 0"]
-
-
-def k_reads(kset):
+def k_reads(kset, slot):
     out = []
     for t in range(2):
         for kk in range(4):
-            out.append(f"ds_read_b128 {ar(KF(kset, t, kk), 4)}, {vr(CKA + kk)} offset:{t * 4096}")
+            out.append(f"ds_read_b128 {ar(KF(kset, t, kk), 4)}, {vr(KA + kk)} offset:{slot * SLOT + t * 4096}")
     return out
 
 
-def v_reads(vset):
+def v_reads(vset, slot):
     out = []
     for ss in range(4):
         for dt in range(2):
             for r in range(2):
-                out.append(f"ds_read_b64_tr_b16 {ar(VF(vset, dt, ss) + 2 * r, 2)}, {vr(CVA + dt * 2 + r)} offset:{ss * 2048}")
+                out.append(f"ds_read_b64_tr_b16 {ar(VF(vset, dt, ss) + 2 * r, 2)}, {vr(VA + dt * 2 + r)} offset:{slot * SLOT + ss * 2048}")
     return out
 
 
-def segment(X, Y, kset, vset, reads, dma):
-    """16 MFMAs on tile Y beside the softmax of tile X.  reads: 16 or 8 LDS reads placed in the first 8 gaps;
-    dma: [(gap, instruction list)]."""
+def spread(n, gaps):
+    """n items over the listed gaps, as evenly as integers allow: {gap: count}."""
+    out = {}
+    for i, g in enumerate(gaps):
+        out[g] = (n * (i + 1)) // len(gaps) - (n * i) // len(gaps)
+    return out
+
+
+def segment(X, Y, kset, vset, reads, read_gaps, dma, hooks):
+    """20 MFMAs on tile Y beside the softmax of tile X.  reads: 16 or 8 LDS reads spread over the gaps read_gaps = (first, end);
+    dma: {gap: (ring base sgpr, LDS byte offset, source offset vgpr, source pointer sgpr pair, tile index sgpr)};
+    hooks: {gap: function emitting that gap's scalar bookkeeping} -- everything an iteration needs besides the softmax rides in
+    MFMA gaps, the segment boundaries hold only the rescale test."""
     sx = S[X]
-    la, lb = LSUM[X]
     mx = max_chain(Y)
-    per = len(reads) // 8
-    for g in range(16):
+    if VAR["no_lds"]:
+        reads = []
+    reads = list(reads)
+    n_rd = spread(len(reads), list(range(*read_gaps)))
+    n_exp = spread(32, list(range(20)))
+    # row maximum of S_Y: its first half is complete behind MFMA 3, the second behind MFMA 7 (+ the MFMA -> VALU distance);
+    # it starts behind the hidden-key test of gap 8, so a masked tile needs no second pass
+    n_max = spread(16, list(range(9, 20)))
+    done_exp, done_cvt, done_max = 0, 0, 0
+    for g in range(20):
+        if g in dma and not VAR["no_dma"]:
+            base, off = dma[g][0], dma[g][1]
+            e(f"s_add_u32 m0, {sr(base)}, {off}")
         e(mfma_qk(Y, kset, g) if g < 8 else mfma_pv(Y, vset, g - 8))
-        if g < 8:
-            for i in range(per):
-                e(reads[g * per + i])
-        e(f"v_exp_f32 {vr(sx + 2 * g)}, {vr(sx + 2 * g)}")
-        if g >= 8:
-            e(mx[2 * (g - 8)])
-        if g > 0:
-            e(f"v_add_f32 {vr(la)}, {vr(la)}, {vr(sx + 2 * g - 2)}")
-        e(f"v_exp_f32 {vr(sx + 2 * g + 1)}, {vr(sx + 2 * g + 1)}")
-        if g > 0:
-            e(f"v_add_f32 {vr(lb)}, {vr(lb)}, {vr(sx + 2 * g - 1)}")
-            e(f"v_cvt_pk_bf16_f32 {vr(P[X] + g - 1)}, {vr(sx + 2 * g - 2)}, {vr(sx + 2 * g - 1)}")
-        if g >= 8:
-            e(mx[2 * (g - 8) + 1])
-        for gg, ins in dma:
-            if gg == g:
-                for i in ins:
-                    e(i)
-    e(f"v_add_f32 {vr(la)}, {vr(la)}, {vr(sx + 30)}")
-    e("s_nop 0")
-    e(f"v_add_f32 {vr(lb)}, {vr(lb)}, {vr(sx + 31)}")
-    e(f"v_cvt_pk_bf16_f32 {vr(P[X] + 15)}, {vr(sx + 30)}, {vr(sx + 31)}")
+        for _ in range(n_rd.get(g, 0)):
+            e(reads.pop(0))
+        # a pair is packed one gap after its second exponential (the transcendental result needs a wait state before its use)
+        ready = done_exp // 2
+        for _ in range(n_exp[g]):
+            if not VAR["no_softmax"] and not VAR["no_exp"]:
+                e(f"v_exp_f32 {vr(sx + done_exp)}, {vr(sx + done_exp)}")
+            done_exp += 1
+            if done_cvt < ready:
+                if not VAR["no_softmax"] and not VAR["no_cvtmax"]:
+                    e(f"v_cvt_pk_bf16_f32 {vr(P[X] + done_cvt)}, {vr(sx + 2 * done_cvt)}, {vr(sx + 2 * done_cvt + 1)}")
+                done_cvt += 1
+            if done_max < 16 and n_max.get(g, 0) > 0:
+                if not VAR["no_softmax"] and not VAR["no_cvtmax"]:
+                    e(mx[done_max])
+                done_max += 1
+                n_max[g] -= 1
+        while n_max.get(g, 0) > 0:
+            if not VAR["no_softmax"] and not VAR["no_cvtmax"]:
+                e(mx[done_max])
+            done_max += 1
+            n_max[g] -= 1
+        if g in hooks:
+            hooks[g]()
+        if g in dma and not VAR["no_dma"]:
+            _, _, voff, ptr, tile = dma[g]
+            skip = lab("nodma")
+            e(f"s_cmp_lt_u32 {sr(tile)}, {sr(NIT)}")
+            e(f"s_cbranch_scc0 {skip}")
+            e(f"global_load_lds_dwordx4 {vr(voff)}, {sr(ptr, 2)}")
+            e(f"{skip}:")
+    assert done_exp == 32 and done_max == 16 and not reads
+    while done_cvt < 16:
+        if done_cvt == 15:
+            e("s_nop 0")
+        if not VAR["no_softmax"] and not VAR["no_cvtmax"]:
+            e(f"v_cvt_pk_bf16_f32 {vr(P[X] + done_cvt)}, {vr(sx + 2 * done_cvt)}, {vr(sx + 2 * done_cvt + 1)}")
+        done_cvt += 1
 
 
-def slow_path(X):
-    """Exact online-softmax update of tile X's reference m (per query): scores, sums and O move to the new reference."""
+def sub_slow(X, name):
+    """Subroutine: exact online-softmax update of tile X's reference m (per query); scores, row sums and O move to the new reference."""
     t0, t1, t2, t3, t4, t5 = T[:6]
     m, seen, mloc = MREF[X], SEEN[X], MLOC[X]
-    e("s_nop 15")                                   # MFMA -> VALU distance for O
-    e(f"v_mov_b32 {vr(t0)}, {vr(mloc)}")
-    e(f"v_mov_b32 {vr(t1)}, {vr(mloc)}")
-    e("s_nop 1")
-    e(f"v_permlane32_swap_b32 {vr(t0)}, {vr(t1)}")
-    e(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")                      # mx: the query's maximum, relative to m
-    e(f"v_max_f32 {vr(t1)}, 0, {vr(t0)}")                             # seen: delta = max(mx, 0)
-    e(f"v_cmp_neq_f32 vcc, {NINF}, {vr(t0)}")
-    e(f"v_cndmask_b32 {vr(t2)}, 0, {vr(t0)}, vcc")                    # not seen: delta = mx (0 if no visible key yet)
-    e(f"v_cndmask_b32_e64 {vr(t5)}, 0, 1, vcc")
-    e(f"v_cmp_ne_u32 vcc, 0, {vr(seen)}")
-    e(f"v_cndmask_b32 {vr(t3)}, {vr(t2)}, {vr(t1)}, vcc")             # delta
-    e(f"v_exp_f32 {vr(t4)}, -{vr(t3)}")
-    e(f"v_or_b32 {vr(seen)}, {vr(seen)}, {vr(t5)}")
-    e(f"v_add_f32 {vr(m)}, {vr(m)}, {vr(t3)}")
-    e(f"v_cndmask_b32 {vr(t4)}, 1.0, {vr(t4)}, vcc")                  # alpha (1 while nothing was accumulated)
+    o = TAIL.append
+    o(f"{name}:")
+    o("s_nop 15")                                   # MFMA -> VALU distance for O and the row sums
+    o(f"v_mov_b32 {vr(t0)}, {vr(mloc)}")
+    o(f"v_mov_b32 {vr(t1)}, {vr(mloc)}")
+    o("s_nop 1")
+    o(f"v_permlane32_swap_b32 {vr(t0)}, {vr(t1)}")
+    o(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")                      # mx: the query's maximum, relative to m
+    o(f"v_max_f32 {vr(t1)}, 0, {vr(t0)}")                             # seen: delta = max(mx, 0)
+    o(f"v_cmp_neq_f32 vcc, {NINF}, {vr(t0)}")
+    o(f"v_cndmask_b32 {vr(t2)}, 0, {vr(t0)}, vcc")                    # not seen: delta = mx (0 if no visible key yet)
+    o(f"v_cndmask_b32_e64 {vr(t5)}, 0, 1, vcc")
+    o(f"v_cmp_ne_u32 vcc, 0, {vr(seen)}")
+    o(f"v_cndmask_b32 {vr(t3)}, {vr(t2)}, {vr(t1)}, vcc")             # delta
+    o(f"v_exp_f32 {vr(t4)}, -{vr(t3)}")
+    o(f"v_or_b32 {vr(seen)}, {vr(seen)}, {vr(t5)}")
+    o(f"v_add_f32 {vr(m)}, {vr(m)}, {vr(t3)}")
+    o(f"v_cndmask_b32 {vr(t4)}, 1.0, {vr(t4)}, vcc")                  # alpha (1 while nothing was accumulated)
     for i in range(16):
-        e(f"v_sub_f32 {vr(NEGM[X] + i)}, 0, {vr(m)}")
+        o(f"v_sub_f32 {vr(NEGM[X] + i)}, 0, {vr(m)}")
     for r in range(32):
-        e(f"v_sub_f32 {vr(S[X] + r)}, {vr(S[X] + r)}, {vr(t3)}")
-    e(f"v_sub_f32 {vr(mloc)}, {vr(mloc)}, {vr(t3)}")
-    for l in LSUM[X]:
-        e(f"v_mul_f32 {vr(l)}, {vr(l)}, {vr(t4)}")
-    for dt in range(2):
-        for r in range(16):
-            a = O[X][dt] + r
-            tt = T[6 + (r & 1)]
-            e(f"v_accvgpr_read_b32 {vr(tt)}, {ar(a)}")
-            e("s_nop 0")
-            e(f"v_mul_f32 {vr(tt)}, {vr(tt)}, {vr(t4)}")
-            e("s_nop 0")
-            e(f"v_accvgpr_write_b32 {ar(a)}, {vr(tt)}")
-    e("s_nop 3")
+        o(f"v_sub_f32 {vr(S[X] + r)}, {vr(S[X] + r)}, {vr(t3)}")
+    o(f"v_sub_f32 {vr(mloc)}, {vr(mloc)}, {vr(t3)}")
+    regs = [O[X][dt] + r for dt in range(2) for r in range(16)] + [LACC[X]]      # (only register 0 of the row sums is read at the end)
+    for i, a in enumerate(regs):
+        tt = T[6 + (i & 1)]
+        o(f"v_accvgpr_read_b32 {vr(tt)}, {ar(a)}")
+        o(f"v_mul_f32 {vr(tt)}, {vr(tt)}, {vr(t4)}")
+        o(f"v_accvgpr_write_b32 {ar(a)}, {vr(tt)}")
+    o("s_nop 3")
+    o(f"s_setpc_b64 {sr(RET, 2)}")
 
 
-def decide(X, causal):
-    """Top of tile X's softmax segment: take the slow path on the first tile, for a non-prefix mask, or when a score is 2^8 above m."""
-    slow, fast = lab("slow"), lab("fast")
-    e(f"v_cmp_lt_f32 vcc, {SLACK}, {vr(MLOC[X])}")
-    e(f"s_cmp_eq_u32 {sr(J)}, 0")
-    e(f"s_cbranch_scc1 {slow}")
-    e(f"s_bitcmp1_b32 {sr(FLAGS)}, 1")
-    e(f"s_cbranch_scc1 {slow}")
-    e(f"s_cbranch_vccz {fast}")
-    e(f"{slow}:")
-    slow_path(X)
-    e(f"{fast}:")
-
-
-def mask_tile(Y, tile_s, causal):
-    """After the segment that produced S_Y(tile): if the tile holds a key hidden from a query of this wave, set those scores to
-    -inf and redo the row maximum.  Visibility comes from the mask bytes (prefix or not) and, causal, the query index."""
-    done = lab("nomask")
+def sub_mask(Y, name, causal):
+    """Subroutine (KB = 64 * tile): set the scores of tile Y's hidden keys to -inf (called before the row maximum is taken).
+    Visibility comes from the mask bytes (prefix or not) and, causal, the query index."""
     t0, t1, t2, t3 = T[:4]
-    # wave-uniform test
-    e(f"s_lshr_b32 {sr(MF)}, {sr(FLAGS)}, 1")                                    # not a prefix: every tile
-    e(f"s_cmp_eq_u32 {sr(tile_s)}, {sr(NITM1)}")
-    e(f"s_cselect_b32 {sr(TMP)}, {sr(FLAGS)}, 0")
-    e(f"s_or_b32 {sr(MF)}, {sr(MF)}, {sr(TMP)}")                                 # the last tile when it is partial (bit 0) / not a prefix
-    e(f"s_lshl_b32 {sr(KB)}, {sr(tile_s)}, 6")
+    o = TAIL.append
+    ret = lab("mret")
+    o(f"{name}:")
+    o(f"s_lshr_b32 {sr(TMP)}, {sr(KB)}, 6")
+    o(f"s_cmp_ge_u32 {sr(TMP)}, {sr(NIT)}")                                      # scores of a tile past the end are never used
+    o(f"s_cbranch_scc1 {ret}")
+    o(f"v_add_u32 {vr(t0)}, {sr(KB)}, {vr(LANE)}")
+    o(f"v_cmp_gt_u32 {sr(CC, 2)}, {sr(SEQ)}, {vr(t0)}")
+    o(f"s_sub_u32 {sr(TMP)}, {sr(SEQ)}, 1")
+    o(f"v_min_u32 {vr(t0)}, {sr(TMP)}, {vr(t0)}")
+    o(f"global_load_ubyte {vr(t1)}, {vr(t0)}, {sr(MPTR, 2)}")
+    o("s_waitcnt vmcnt(0)")
+    o(f"v_cmp_ne_u32 vcc, 0, {vr(t1)}")
+    o(f"s_and_b64 {sr(VIS, 2)}, vcc, {sr(CC, 2)}")
+    o(f"v_lshrrev_b64 {vr(W[0], 2)}, {vr(HH8)}, {sr(VIS, 2)}")
     if causal:
-        e(f"s_add_u32 {sr(TMP)}, {sr(KB)}, 63")
-        e(f"s_cmp_gt_u32 {sr(TMP)}, {sr(Q0)}")                                   # the tile reaches this wave's diagonal
-        e(f"s_cselect_b32 {sr(TMP)}, 1, 0")
-        e(f"s_or_b32 {sr(MF)}, {sr(MF)}, {sr(TMP)}")
-    e(f"s_cmp_lt_u32 {sr(tile_s)}, {sr(NIT)}")
-    e(f"s_cselect_b32 {sr(MF)}, {sr(MF)}, 0")
-    e(f"s_cmp_eq_u32 {sr(MF)}, 0")
-    e(f"s_cbranch_scc1 {done}")
-    # 64-bit visibility of the tile's keys
-    e(f"v_add_u32 {vr(t0)}, {sr(KB)}, {vr(LANE)}")
-    e(f"v_cmp_gt_u32 {sr(CC, 2)}, {sr(SEQ)}, {vr(t0)}")
-    e(f"s_sub_u32 {sr(TMP)}, {sr(SEQ)}, 1")
-    e(f"v_min_u32 {vr(t0)}, {sr(TMP)}, {vr(t0)}")
-    e(f"global_load_ubyte {vr(t1)}, {vr(t0)}, {sr(MPTR, 2)}")
-    e("s_waitcnt vmcnt(0)")
-    e(f"v_cmp_ne_u32 vcc, 0, {vr(t1)}")
-    e(f"s_and_b64 {sr(VIS, 2)}, vcc, {sr(CC, 2)}")
-    e(f"v_lshrrev_b64 {vr(W[0], 2)}, {vr(HH8)}, {sr(VIS, 2)}")
-    if causal:
-        e(f"v_subrev_u32 {vr(t2)}, {sr(KB)}, {vr(CQ[Y])}")                       # keys below this bit index are visible
-        e(f"v_med3_i32 {vr(t2)}, {vr(t2)}, 0, 56")
-        e(f"v_lshlrev_b64 {vr(LM[0], 2)}, {vr(t2)}, 1")
-        e(f"v_add_co_u32 {vr(LM[0])}, vcc, -1, {vr(LM[0])}")
-        e(f"v_addc_co_u32 {vr(LM[1])}, vcc, -1, {vr(LM[1])}, vcc")
-        e(f"v_and_b32 {vr(W[0])}, {vr(W[0])}, {vr(LM[0])}")
-        e(f"v_and_b32 {vr(W[1])}, {vr(W[1])}, {vr(LM[1])}")
-    e(f"v_mov_b32 {vr(NINFV)}, {NINF}")
+        o(f"v_subrev_u32 {vr(t2)}, {sr(KB)}, {vr(CQ[Y])}")                       # keys below this bit index are visible
+        o(f"v_med3_i32 {vr(t2)}, {vr(t2)}, 0, 56")
+        o(f"v_lshlrev_b64 {vr(LM[0], 2)}, {vr(t2)}, 1")
+        o(f"v_add_co_u32 {vr(LM[0])}, vcc, -1, {vr(LM[0])}")
+        o(f"v_addc_co_u32 {vr(LM[1])}, vcc, -1, {vr(LM[1])}, vcc")
+        o(f"v_and_b32 {vr(W[0])}, {vr(W[0])}, {vr(LM[0])}")
+        o(f"v_and_b32 {vr(W[1])}, {vr(W[1])}, {vr(LM[1])}")
+    o(f"v_mov_b32 {vr(NINFV)}, {NINF}")
     for r in range(32):
         t, rr = r >> 4, r & 15
         c = 16 * (rr >> 3) + (rr & 7)
         tt = T[2 + (r & 1)]
-        e(f"v_bfe_i32 {vr(tt)}, {vr(W[t])}, {c}, 1")
-        e(f"v_bfi_b32 {vr(S[Y] + r)}, {vr(tt)}, {vr(S[Y] + r)}, {vr(NINFV)}")
-    for i in max_chain(Y):
-        e(i)
-    e(f"{done}:")
+        o(f"v_bfe_i32 {vr(tt)}, {vr(W[t])}, {c}, 1")
+        o(f"v_bfi_b32 {vr(S[Y] + r)}, {vr(tt)}, {vr(S[Y] + r)}, {vr(NINFV)}")
+    o(f"{ret}:")
+    o(f"s_setpc_b64 {sr(RET, 2)}")
+
+
+def sub_tail(name, dv):
+    o = TAIL.append
+    o(f"{name}:")
+    o(f"v_mov_b32 {vr(dv)}, {vr(VOFF + 2)}")
+    o(f"v_mov_b32 {vr(dv + 1)}, {vr(VOFF + 3)}")
+    o(f"s_setpc_b64 {sr(RET, 2)}")
+
+
+SUBS = {}
+
+
+def decide(X):
+    """Top of tile X's softmax segment: rescale when a score is more than SLK above the reference (SLK = -inf on the first
+    tile and for a mask that is not a prefix: every lane that saw a key takes the exact path)."""
+    e(f"v_cmp_lt_f32 vcc, {sr(SLK)}, {vr(MLOC[X])}")
+    call("s_cbranch_vccnz", SUBS["slow" + X])
+
+
+def mask_check(Y, tile_s):
+    e(f"s_cmp_ge_u32 {sr(tile_s)}, {sr(MFROM)}")
+    call("s_cbranch_scc1", SUBS["mask" + Y], pre=[f"s_lshl_b32 {sr(KB)}, {sr(tile_s)}, 6"])
 
 
 def barrier_wait():
     """Pieces still allowed in flight when tile pair j is needed: 2 * min(n_it - 1 - j, 4)."""
-    labs = {n: lab(f"w{n}") for n in (8, 6, 4, 2)}
+    labs = {n: lab(f"w{n}") for n in (6, 4, 2, 0)}
     bar = lab("bar")
-    e("s_waitcnt lgkmcnt(0)")
     e(f"s_sub_u32 {sr(R)}, {sr(NITM1)}, {sr(J)}")
-    e(f"s_cmp_ge_u32 {sr(R)}, 4")
-    e(f"s_cbranch_scc1 {labs[8]}")
-    e(f"s_cmp_eq_u32 {sr(R)}, 3")
+    e(f"s_cmp_lt_u32 {sr(R)}, 4")
     e(f"s_cbranch_scc1 {labs[6]}")
-    e(f"s_cmp_eq_u32 {sr(R)}, 2")
-    e(f"s_cbranch_scc1 {labs[4]}")
-    e(f"s_cmp_eq_u32 {sr(R)}, 1")
-    e(f"s_cbranch_scc1 {labs[2]}")
-    e("s_waitcnt vmcnt(0)")
-    e(f"s_branch {bar}")
-    for n in (2, 4, 6):
-        e(f"{labs[n]}:")
-        e(f"s_waitcnt vmcnt({n})")
-        e(f"s_branch {bar}")
-    e(f"{labs[8]}:")
     e("s_waitcnt vmcnt(8)")
     e(f"{bar}:")
     e("s_barrier")
+    o = TAIL.append
+    o(f"{labs[6]}:")
+    o(f"s_cmp_eq_u32 {sr(R)}, 3")
+    o(f"s_cbranch_scc0 {labs[4]}")
+    o("s_waitcnt vmcnt(6)")
+    o(f"s_branch {bar}")
+    o(f"{labs[4]}:")
+    o(f"s_cmp_eq_u32 {sr(R)}, 2")
+    o(f"s_cbranch_scc0 {labs[2]}")
+    o("s_waitcnt vmcnt(4)")
+    o(f"s_branch {bar}")
+    o(f"{labs[2]}:")
+    o(f"s_cmp_eq_u32 {sr(R)}, 1")
+    o(f"s_cbranch_scc0 {labs[0]}")
+    o("s_waitcnt vmcnt(2)")
+    o(f"s_branch {bar}")
+    o(f"{labs[0]}:")
+    o("s_waitcnt vmcnt(0)")
+    o(f"s_branch {bar}")
 
 
-def iteration(par, causal):
-    barrier_wait()
-    # ring slots of this iteration: read V(j) from slot j & 3, K(j+2) from (j+2) & 3; write V(j+3), K(j+5)
-    e(f"s_and_b32 {sr(TMP)}, {sr(J)}, 3")
-    e(f"s_lshl_b32 {sr(SL)}, {sr(TMP)}, 13")
-    e(f"s_xor_b32 {sr(SL2)}, {sr(SL)}, 0x4000")
-    e(f"s_add_u32 {sr(TV)}, {sr(J)}, 3")
-    e(f"s_add_u32 {sr(TK)}, {sr(J)}, 5")
-    e(f"s_and_b32 {sr(TMP)}, {sr(TV)}, 3")
-    e(f"s_lshl_b32 {sr(SL3)}, {sr(TMP)}, 13")
-    e(f"s_and_b32 {sr(TMP)}, {sr(TK)}, 3")
-    e(f"s_lshl_b32 {sr(SL1)}, {sr(TMP)}, 13")
-    for i in range(4):
-        e(f"v_add_u32 {vr(CVA + i)}, {sr(SL)}, {vr(VA + i)}")
-    for i in range(4):
-        e(f"v_add_u32 {vr(CKA + i)}, {sr(SL2)}, {vr(KA + i)}")
+def iteration(c, end_label):
+    """Iteration j with j = c (mod 4): reads V(j) from slot c and K(j+2) from slot c ^ 2, writes V(j+3) and K(j+5).
+    The tile barrier sits in gap 1 of segment 1: nothing ahead of it needs tile pair j (QK_B(j) runs on fragments read an
+    iteration ago, the softmax on registers)."""
+    par = c & 1
+    sv, sk = (c + 3) & 3, (c + 1) & 3
+    g0, g1 = VAR["dma_gaps"]
+    stamp(6)
+    e("s_waitcnt lgkmcnt(0)")
     # segment 1: softmax A(j) beside QK_B(j), PV_B(j-1)
-    decide("A", causal)
-    e(f"s_add_u32 {sr(DST)}, {sr(LDSV)}, {sr(SL3)}")
-    segment("A", "B", par, 1 - par, v_reads(par),
-            [(3, dma_piece(TV, DST, VPTR, 0)), (11, dma_piece(TV, DST, VPTR, 1) + advance(VPTR))])
-    mask_tile("B", J, causal)
+    decide("A")
+    stamp(2)
+
+    def tile_v():
+        e(f"s_add_u32 {sr(TV)}, {sr(J)}, 3")
+        e(f"s_cmp_eq_u32 {sr(TV)}, {sr(TAILT)}")
+        call("s_cbranch_scc1", SUBS["tailV"])
+
+    def adv_v():
+        e(f"s_add_u32 {sr(VPTR)}, {sr(VPTR)}, {SLOT}")
+        e(f"s_addc_u32 {sr(VPTR + 1)}, {sr(VPTR + 1)}, 0")
+
+    segment("A", "B", par, 1 - par, v_reads(par, c), (2, 10),
+            {g0: (LDSV, sv * SLOT, DVV, VPTR, TV), g1: (LDSV, sv * SLOT + 4096, DVV + 1, VPTR, TV)},
+            {1: barrier_wait, 3: tile_v, 8: lambda: mask_check("B", J), g1 + 1: adv_v})
+    stamp(3)
     e("s_waitcnt lgkmcnt(0)")
     # segment 2: softmax B(j) beside QK_A(j+1), PV_A(j)
-    decide("B", causal)
-    e(f"s_add_u32 {sr(DST)}, {sr(LDSK)}, {sr(SL1)}")
-    segment("B", "A", 1 - par, par, k_reads(par),
-            [(3, dma_piece(TK, DST, KPTR, 0)), (11, dma_piece(TK, DST, KPTR, 1) + advance(KPTR))])
-    e(f"s_add_u32 {sr(TMP2)}, {sr(J)}, 1")
-    mask_tile("A", TMP2, causal)
+    decide("B")
+    stamp(4)
+
+    def tile_k():
+        e(f"s_add_u32 {sr(TK)}, {sr(J)}, 5")
+        e(f"s_cmp_eq_u32 {sr(TK)}, {sr(TAILT)}")
+        call("s_cbranch_scc1", SUBS["tailK"])
+
+    def adv_k():
+        e(f"s_add_u32 {sr(KPTR)}, {sr(KPTR)}, {SLOT}")
+        e(f"s_addc_u32 {sr(KPTR + 1)}, {sr(KPTR + 1)}, 0")
+
+    def loop_ctl():
+        e(f"s_add_u32 {sr(J)}, {sr(J)}, 1")
+        if c == 0:
+            e(f"s_mov_b32 {sr(SLK)}, {sr(SLKS)}")         # past the first tile: the lazy threshold
+
+    def loop_cmp():
+        e(f"s_add_u32 {sr(J1)}, {sr(J1)}, 1")
+        e(f"s_cmp_ge_u32 {sr(J)}, {sr(NIT)}")              # SCC holds until the branch behind the segment
+
+    segment("B", "A", 1 - par, par, k_reads(par, c ^ 2), (0, 8),
+            {g0: (LDSK, sk * SLOT, DVK, KPTR, TK), g1: (LDSK, sk * SLOT + 4096, DVK + 1, KPTR, TK)},
+            {2: tile_k, 8: lambda: mask_check("A", J1), g1 + 1: adv_k, 18: loop_ctl, 19: loop_cmp})
+    stamp(5)
+    if DIAG[0]:
+        e(f"s_cmp_ge_u32 {sr(J)}, {sr(NIT)}")
+    e(f"s_cbranch_scc1 {end_label}")
 
 
 def prologue(causal):
     fin0 = lab("fin0")
-    # lane, zeroed state
+    if DIAG[0]:
+        for k in range(8):
+            e(f"s_mov_b32 {sr(ACC0 + k)}, 0")
+        e(f"s_memtime {sr(CUR, 2)}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_mov_b32 {sr(PREV)}, {sr(CUR)}")
+    e(f"s_sub_u32 {sr(NITM1)}, {sr(NIT)}, 1")
+    e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
+    e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
+    for i in range(2):
+        e(f"v_mov_b32 {vr(DVK + i)}, {vr(VOFF + i)}")
+        e(f"v_mov_b32 {vr(DVV + i)}, {vr(VOFF + i)}")
+    # Q fragments first (vmcnt completes in order: any wait that covers a K/V piece covers them)
+    for X in "AB":
+        for kk in range(4):
+            e(f"global_load_dwordx4 {ar(Q[X] + 4 * kk, 4)}, {vr(QOFF[X])}, {sr(QPTR, 2)} offset:{32 * kk}")
+
+    # K0 K1 | V0 K2 | V1 K3   (slot = tile & 3)
+    def tile_dma(kind, tile):
+        ptr, base, dv = (KPTR, LDSK, DVK) if kind == "K" else (VPTR, LDSV, DVV)
+        skip = lab("nopro")
+        e(f"s_cmp_le_u32 {sr(NIT)}, {tile}")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u32 {sr(TAILT)}, {tile}")
+        call("s_cbranch_scc1", SUBS["tail" + kind])
+        for p in range(2):
+            e(f"s_add_u32 m0, {sr(base)}, {(tile & 3) * SLOT + p * 4096}")
+            e("s_nop 0")
+            e(f"global_load_lds_dwordx4 {vr(dv + p)}, {sr(ptr, 2)}")
+        e(f"{skip}:")
+        e(f"s_add_u32 {sr(ptr)}, {sr(ptr)}, {SLOT}")
+        e(f"s_addc_u32 {sr(ptr + 1)}, {sr(ptr + 1)}, 0")
+    for kind, tile in (("K", 0), ("K", 1), ("V", 0), ("K", 2), ("V", 1), ("K", 3)):
+        tile_dma(kind, tile)
+    # zeroed state, under the flight of the first tiles
     for X in "AB":
         for dt in range(2):
             for r in range(16):
                 e(f"v_accvgpr_write_b32 {ar(O[X][dt] + r)}, 0")
+        for r in range(16):
+            e(f"v_accvgpr_write_b32 {ar(LACC[X] + r)}, 0")
         for i in range(16):
             e(f"v_mov_b32 {vr(NEGM[X] + i)}, 0")
-        for l in LSUM[X]:
-            e(f"v_mov_b32 {vr(l)}, 0")
         e(f"v_mov_b32 {vr(MREF[X])}, 0")
         e(f"v_mov_b32 {vr(SEEN[X])}, 0")
     for i in range(16):
@@ -378,27 +493,22 @@ def prologue(causal):
         for ss in range(4):
             for r in range(4):
                 e(f"v_accvgpr_write_b32 {ar(VF(1, dt, ss) + r)}, 0")
+    for i in range(4):
+        e(f"v_mov_b32 {vr(ONEV + i)}, {ONES}")
+    # lazy-rescale threshold: 8 (log2 units); -inf on the first tile and for non-prefix masks.  Tiles from MFROM on hold hidden keys.
+    e(f"s_mov_b32 {sr(SLK)}, {NINF}")
+    e(f"s_mov_b32 {sr(SLKS)}, 0x41000000")
+    e(f"s_bitcmp1_b32 {sr(FLAGS)}, 1")
+    e(f"s_cselect_b32 {sr(SLKS)}, {sr(SLK)}, {sr(SLKS)}")
+    e(f"s_bitcmp1_b32 {sr(FLAGS)}, 0")
+    e(f"s_cselect_b32 {sr(MFROM)}, {sr(NITM1)}, {sr(NIT)}")                       # partial last tile
+    e(f"s_bitcmp1_b32 {sr(FLAGS)}, 1")
+    e(f"s_cselect_b32 {sr(MFROM)}, 0, {sr(MFROM)}")                               # not a prefix: every tile
+    if causal:
+        e(f"s_lshr_b32 {sr(TMP)}, {sr(Q0)}, 6")                                   # tiles from q0 / 64 on reach this wave's diagonal
+        e(f"s_min_u32 {sr(MFROM)}, {sr(MFROM)}, {sr(TMP)}")
     e(f"s_cmp_eq_u32 {sr(NIT)}, 0")
     e(f"s_cbranch_scc1 {fin0}")
-    e(f"s_sub_u32 {sr(NITM1)}, {sr(NIT)}, 1")
-    e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
-    e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
-    # Q fragments first (vmcnt completes in order: any wait that covers a K/V piece covers them)
-    for X in "AB":
-        for kk in range(4):
-            e(f"global_load_dwordx4 {ar(Q[X] + 4 * kk, 4)}, {vr(QOFF[X])}, {sr(QPTR, 2)} offset:{32 * kk}")
-    # K0 K1 | V0 K2 | V1 K3   (slot = tile & 3)
-    def tile_dma(kind, tile):
-        ptr, base = (KPTR, LDSK) if kind == "K" else (VPTR, LDSV)
-        e(f"s_mov_b32 {sr(TK)}, {tile}")
-        e(f"s_add_u32 {sr(DST)}, {sr(base)}, {(tile & 3) * SLOT}")
-        for p in range(2):
-            for i in dma_piece(TK, DST, ptr, p):
-                e(i)
-        for i in advance(ptr):
-            e(i)
-    for kind, tile in (("K", 0), ("K", 1), ("V", 0), ("K", 2), ("V", 1), ("K", 3)):
-        tile_dma(kind, tile)
     w8, wb = lab("pw8"), lab("pwb")
     e(f"s_cmp_ge_u32 {sr(NIT)}, 4")
     e(f"s_cbranch_scc1 {w8}")
@@ -410,9 +520,7 @@ def prologue(causal):
     e("s_barrier")
     # K(0) -> set 0, K(1) -> set 1
     for st in range(2):
-        for i in range(4):
-            e(f"v_add_u32 {vr(CKA + i)}, {st * SLOT}, {vr(KA + i)}")
-        for i in k_reads(st):
+        for i in k_reads(st, st):
             e(i)
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")                                   # every wave has K(0) in registers: slot 0 may take K(4)
@@ -421,62 +529,96 @@ def prologue(causal):
     for i in range(8):
         e(mfma_qk("A", 0, i))
     e("s_nop 15")
+    e(f"s_mov_b32 {sr(J)}, 0")
+    e(f"s_mov_b32 {sr(J1)}, 1")
+    mask_check("A", J)
     for i in max_chain("A"):
         e(i)
-    e(f"s_mov_b32 {sr(J)}, 0")
-    e(f"s_mov_b32 {sr(TMP2)}, 0")
-    mask_tile("A", TMP2, causal)
+    stamp(0)
     return fin0
 
 
-def body(causal):
+def body(causal, diag=False):
     del L[:]
+    del TAIL[:]
+    DIAG[0] = diag
+    for k in ("slowA", "slowB", "maskA", "maskB", "tailK", "tailV"):
+        SUBS[k] = lab(k)
     fin0 = prologue(causal)
-    loop, end0, end1, fin = lab("loop"), lab("end0"), lab("end1"), lab("fin")
+    loop, ends, fin, done = lab("loop"), [lab("end0"), lab("end1")], lab("fin"), lab("done")
     e(f"{loop}:")
-    iteration(0, causal)
-    e(f"s_add_u32 {sr(J)}, {sr(J)}, 1")
-    e(f"s_cmp_ge_u32 {sr(J)}, {sr(NIT)}")
-    e(f"s_cbranch_scc1 {end0}")
-    iteration(1, causal)
-    e(f"s_add_u32 {sr(J)}, {sr(J)}, 1")
-    e(f"s_cmp_lt_u32 {sr(J)}, {sr(NIT)}")
-    e(f"s_cbranch_scc1 {loop}")
-    e(f"{end1}:")
-    for i in range(8):
+    for c in range(4):
+        iteration(c, ends[c & 1])
+    e(f"s_branch {loop}")
+    e(f"{ends[1]}:")
+    for i in range(12):
         e(mfma_pv("B", 1, i))
     e(f"s_branch {fin}")
-    e(f"{end0}:")
-    for i in range(8):
+    e(f"{ends[0]}:")
+    for i in range(12):
         e(mfma_pv("B", 0, i))
     e(f"{fin}:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    stamp(7)
     e(f"{fin0}:")
     e("s_nop 15")
     e("s_nop 3")
+    e(f"s_branch {done}")
+    sub_slow("A", SUBS["slowA"])
+    sub_slow("B", SUBS["slowB"])
+    sub_mask("A", SUBS["maskA"], causal)
+    sub_mask("B", SUBS["maskB"], causal)
+    sub_tail(SUBS["tailK"], DVK)
+    sub_tail(SUBS["tailV"], DVV)
+    for s in TAIL:
+        e(s)
+    e(f"{done}:")
     return list(L)
 
 
 def clobbers():
-    pinned_v = set(range(KA, KA + 4)) | set(range(VA, VA + 4)) | set(range(VOFF, VOFF + 4)) | set(range(154, 160)) \
-        | set(range(128, 134))
-    pinned_s = set(range(36, 52))
+    pinned_v = set(range(KA, KA + 4)) | set(range(VA, VA + 4)) | set(range(VOFF, VOFF + 4)) | set(range(154, 160)) | {132, 133}
     out = [f"v{i}" for i in range(MAXV + 1) if i not in pinned_v]
-    out += [f"a{i}" for i in range(64, MAXA + 1)]
-    out += [f"s{i}" for i in range(MAXS + 1) if i >= 52 or i in (TAILT, NITM1, LDSV)]
+    out += [f"a{i}" for i in range(64, 256) if i not in (LACC["A"], LACC["B"])]
+    out += [f"s{i}" for i in range(MAXS + 1) if (i >= 52 and not 70 <= i <= 81) or i in (TAILT, NITM1, LDSV)]
     out += ["vcc", "scc", "memory"]
-    return out, pinned_s
+    return out
+
+
+def emit_macro(name, lines):
+    return f"#define {name} \\\n" + " \\\n".join('    "' + s + '\\n\\t"' for s in lines) + "\n"
+
+
+DIAG_VARIANTS = [
+    {},                                             # 1: the product's stream, stamped
+    {"no_dma": True},                               # 2: no LDS-DMA in the loop
+    {"no_exp": True},                               # 3: no exponentials
+    {"no_cvtmax": True},                            # 4: exponentials only
+    {"no_softmax": True},                           # 5: MFMA + LDS + DMA only
+    {"qk_agpr": True},                              # 6: QK^T results written to AGPRs (does a VGPR-destination MFMA slow the VALU?)
+    {"no_dma": True, "no_softmax": True, "no_lds": True},   # 7: bare MFMA stream
+    {"dma_gaps": (12, 17)},                         # 8
+]
 
 
 def main():
     parts = ["// GENERATED by tools/gen_attn_fwd64.py -- do not edit.\n"]
     for causal in (0, 1):
         lines = body(causal)
-        parts.append(f"#define P2T_ATTN64_BODY_{causal} \\\n" + " \\\n".join('    "' + s + '\\n\\t"' for s in lines) + "\n")
+        parts.append(emit_macro(f"P2T_ATTN64_BODY_{causal}", lines))
         n_mfma = sum(1 for s in lines if s.startswith("v_mfma"))
         print(f"causal={causal}: {len(lines)} lines, {n_mfma} MFMAs")
-    cl, _ = clobbers()
-    parts.append("#define P2T_ATTN64_CLOBBERS " + ", ".join(f'"{c}"' for c in cl) + "\n")
+    parts.append("#define P2T_ATTN64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    # diagnostic builds (lab library only): per-phase cycle sums in s70..s77, returned as outputs; variants 2.. are ablations
+    # (their results are wrong by construction: what they measure is what the removed part costs)
+    parts.append("#ifdef P2T_LAB\n")
+    base = dict(VAR)
+    for k, over in enumerate(DIAG_VARIANTS):
+        VAR.update(base)
+        VAR.update(over)
+        parts.append(emit_macro(f"P2T_ATTN64_BODY_DIAG{k + 1}", body(0, diag=True)))
+    VAR.update(base)
+    parts.append("#define P2T_ATTN64_CLOBBERS_DIAG P2T_ATTN64_CLOBBERS, \"s78\", \"s80\", \"s81\"\n#endif\n")
     with open(OUT, "w") as f:
         f.write("\n".join(parts))
 
