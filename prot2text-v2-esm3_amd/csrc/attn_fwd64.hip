@@ -30,21 +30,18 @@ constexpr int kA64Lds = kA64Ring + 4 * 8192;                 // + one 64-query x
 __device__ __forceinline__ int a64_perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ int a64_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-template <bool CAUSAL, int DIAG = 0>
-__global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                             const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
-                                                             const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out, int64_t ld_out,
-                                                             int B, int seq, int nh, int nkv, int d, int out_cols, float* lse, int n_blocks) {
-    __shared__ __attribute__((aligned(16))) char smem[kA64Lds];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Persistent: one workgroup per CU walks the query blocks id = blockIdx.x, + gridDim.x, ... (a new workgroup of this size
-    // starts 2.2 us after its predecessor ends -- 9 % of the launch at ten blocks per CU, profiles/r04_attn64_v3_gaps.log).
-    // XCD-aware block order (attn_mfma.hip): the query blocks of one (batch, head) share an L2; gridDim.x is a multiple of 8,
-    // so a workgroup's blocks stay on its XCD's residue.
+// What one query block needs from the index arithmetic (wave-uniform unless noted).
+struct A64Block {
+    int b, h, q0, n_it, flags;
+    uint64_t kptr, vptr, qptr, mptr;
+    i32x4 misc;                   // per lane: Q row offsets of tiles A / B, causal limits of tiles A / B
+};
+
+template <bool CAUSAL>
+__device__ __forceinline__ A64Block a64_block(int id, const bf16_t* q, const bf16_t* k, const bf16_t* v, const uint8_t* key_mask, const int32_t* kv_info,
+                                              int B, int seq, int nh, int nkv, int w, int lane) {
+    // XCD-aware block order (attn_mfma.hip): the query blocks of one (batch, head) share an L2
     const int n_qb = (seq + 255) >> 8, n_hb = nh * B, hb_full = n_hb & ~7;
-    for (int id = blockIdx.x; id < n_blocks; id += gridDim.x) {
-    if (id != (int)blockIdx.x) __builtin_amdgcn_s_barrier();      // every wave is done with the previous block's K / V ring
     int qb, hb;
     if (id < hb_full * n_qb) {
         const int slot = id >> 3;
@@ -55,20 +52,42 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
         hb = hb_full + rid / n_qb;
         qb = rid % n_qb;
     }
-    const int h = hb % nh, b = hb / nh;
-    const int hk = h / (nh / nkv);
-    const int q0 = qb * 256 + w * 64;
-    const int lq = lane & 31, hh = lane >> 5;
-
-    int end = kv_info[b];
-    const int prefix = kv_info[B + b];
+    A64Block r;
+    r.h = hb % nh;
+    r.b = hb / nh;
+    const int hk = r.h / (nh / nkv);
+    r.q0 = qb * 256 + w * 64;
+    int end = kv_info[r.b];
+    const int prefix = kv_info[B + r.b];
     if (CAUSAL) end = min(end, qb * 256 + 256);
     end = min(end, seq);
-    const int n_it = (end + 63) >> 6;
+    r.n_it = (end + 63) >> 6;
+    r.flags = ((end & 63) != 0 ? 1 : 0) | (prefix ? 0 : 2);
+    r.kptr = (uint64_t)(k + ((int64_t)(r.b * nkv + hk) * seq) * 64);
+    r.vptr = (uint64_t)(v + ((int64_t)(r.b * nkv + hk) * seq) * 64);
+    r.qptr = (uint64_t)(q + ((int64_t)(r.b * nh + r.h) * seq) * 64);
+    r.mptr = (uint64_t)(key_mask + (int64_t)r.b * seq);
+    const int lq = lane & 31, hh = lane >> 5;
+    r.misc[0] = min(r.q0 + lq, seq - 1) * 128 + 16 * hh;
+    r.misc[1] = min(r.q0 + 32 + lq, seq - 1) * 128 + 16 * hh;
+    r.misc[2] = r.q0 + lq + 1 - 8 * hh;
+    r.misc[3] = r.q0 + 32 + lq + 1 - 8 * hh;
+    return r;
+}
 
+template <bool CAUSAL, int DIAG = 0>
+__global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                             const bf16_t* __restrict__ v, const uint8_t* __restrict__ key_mask,
+                                                             const int32_t* __restrict__ kv_info, bf16_t* __restrict__ out, int64_t ld_out,
+                                                             int B, int seq, int nh, int nkv, int d, int out_cols, float* lse, int n_blocks) {
+    __shared__ __attribute__((aligned(16))) char smem[kA64Lds];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // ---- per-lane constants of the whole launch ----
     // fragment read addresses (slot 0): K row pi(lq) (+ 32 per tile half), 16-byte chunk (2 kk + hh) ^ g(row)
-    i32x4 ka, va, voffs, misc;
+    i32x4 ka, va, voffs;
     {
         const int row = a64_perm23(lq);
 #pragma unroll
@@ -94,98 +113,115 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
             voffs[i] = row * 128 + chunk;
             voffs[2 + i] = min(row, max(seq - 1 - tail0, 0)) * 128 + chunk;
         }
-        const int qa = min(q0 + lq, seq - 1), qbq = min(q0 + 32 + lq, seq - 1);
-        misc[0] = qa * 128 + 16 * hh;
-        misc[1] = qbq * 128 + 16 * hh;
-        misc[2] = q0 + lq + 1 - 8 * hh;
-        misc[3] = q0 + 32 + lq + 1 - 8 * hh;
     }
-    i32x2 lanes = {8 * hh, lane};
-    uint64_t kptr = (uint64_t)(k + ((int64_t)(b * nkv + hk) * seq) * 64);
-    uint64_t vptr = (uint64_t)(v + ((int64_t)(b * nkv + hk) * seq) * 64);
-    const uint64_t qptr = (uint64_t)(q + ((int64_t)(b * nh + h) * seq) * 64);
-    const uint64_t mptr = (uint64_t)(key_mask + (int64_t)b * seq);
-    const int s_nit = n_it, s_ldsk = (int)(lds0 + w * 1024), s_seq = seq, s_flags = ((end & 63) != 0 ? 1 : 0) | (prefix ? 0 : 2);
-    const int q0s = q0;
+    const int s_ldsk = (int)(lds0 + w * 1024), s_seq = seq;
+    char* stage = smem + kA64Ring + w * 8192;                 // [64 queries][128 B], 16-byte chunk c of row r at c ^ (r & 7)
 
-    f32x16 oA0, oA1, oB0, oB1;
-    float lA, lB;                 // row sums (the ones-row of the PV product: every lane holds its query's whole sum)
-    f32x2 mref;
+    // Persistent: one workgroup per CU walks the query blocks id = blockIdx.x, + gridDim.x, ... (a new workgroup of this size
+    // starts ~2 us after its predecessor ends; gridDim.x is a multiple of 8, so a workgroup's blocks stay on its XCD's residue).
+    // PRE(block) requests the block's Q fragments and first six K / V tiles; it runs BEFORE the previous block's epilogue, whose
+    // ~1.7 us cover the flight (profiles/r04_attn64_v3_gaps.log).  MAIN(block) is the K / V loop; it leaves O^T, the row sums and
+    // the reference exponents in registers for the epilogue.
+    i32x4 dv;                     // DMA source offsets in use (asm state carried from PRE to MAIN)
+    f32x16 qa, qb;                // Q fragments, in flight between PRE and MAIN: nothing but the two statements touches them
+#define P2T_ATTN64_RUN_PRE(BK)                                                                                                          \
+    asm volatile(P2T_ATTN64_PRE                                                                                                         \
+                 : "={v[146:149]}"(dv), "={a[64:79]}"(qa), "={a[80:95]}"(qb), "+{s[36:37]}"(BK.kptr), "+{s[38:39]}"(BK.vptr)          \
+                 : "{s[40:41]}"(BK.qptr), "{s44}"(BK.n_it), "{s45}"(s_ldsk), "{s46}"(s_seq), "{v[150:153]}"(voffs), "{v[154:157]}"(BK.misc) \
+                 : P2T_ATTN64_PRE_CLOBBERS)
+    int id = blockIdx.x;
+    A64Block cur = a64_block<CAUSAL>(id, q, k, v, key_mask, kv_info, B, seq, nh, nkv, w, lane);
+    P2T_ATTN64_RUN_PRE(cur);
+    while (true) {
+        f32x16 oA0, oA1, oB0, oB1;
+        float lA, lB;                 // row sums (the ones-row of the PV product: every lane holds its query's whole sum)
+        f32x2 mref;
 #define P2T_ATTN64_OUTS "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={a224}"(lA), "={a240}"(lB), "={v[132:133]}"(mref), \
-                        "+{s[36:37]}"(kptr), "+{s[38:39]}"(vptr)
-#define P2T_ATTN64_INS "{s[40:41]}"(qptr), "{s[42:43]}"(mptr), "{s44}"(s_nit), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(s_flags), "{s49}"(q0s), \
-                       "{v[138:141]}"(ka), "{v[142:145]}"(va), "{v[150:153]}"(voffs), "{v[154:157]}"(misc), "{v[158:159]}"(lanes)
+                        "+{s[36:37]}"(cur.kptr), "+{s[38:39]}"(cur.vptr), "+{v[146:149]}"(dv)
+#define P2T_ATTN64_INS "{s[42:43]}"(cur.mptr), "{s44}"(cur.n_it), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(cur.flags), "{s49}"(cur.q0), \
+                       "{v[138:141]}"(ka), "{v[142:145]}"(va), "{v[150:153]}"(voffs), "{v[154:157]}"(cur.misc), "{a[64:79]}"(qa), "{a[80:95]}"(qb)
 #ifdef P2T_LAB
-    if constexpr (DIAG != 0) {
-        // diagnostic build: cycles per phase of this wave (tools/gen_attn_fwd64.py, stamp()), written where the log-sum-exps would go
-        const long long t_in = __builtin_amdgcn_s_memtime();
-        const long long r_in = __builtin_amdgcn_s_memrealtime();
-        unsigned c0, c1, c2, c3, c4, c5, c6, c7;
+        i32x4 cyc0, cyc1;
+        long long t_in = 0, r_in = 0;
+        if constexpr (DIAG != 0) {
+            // diagnostic build: cycles per phase of this wave (tools/gen_attn_fwd64.py, stamp()), written where the log-sum-exps would go
+            t_in = __builtin_amdgcn_s_memtime();
+            r_in = __builtin_amdgcn_s_memrealtime();
 #define P2T_ATTN64_DIAG(N)                                                                                                                    \
-        if constexpr (DIAG == N)                                                                                                                  \
-            asm volatile(P2T_ATTN64_BODY_DIAG##N                                                                                                 \
-                         : P2T_ATTN64_OUTS, "={s70}"(c0), "={s71}"(c1), "={s72}"(c2), "={s73}"(c3), "={s74}"(c4), "={s75}"(c5), "={s76}"(c6), "={s77}"(c7) \
-                         : P2T_ATTN64_INS                                                                                                        \
-                         : P2T_ATTN64_CLOBBERS_DIAG);
-        P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8)
+            if constexpr (DIAG == N)                                                                                                              \
+                asm volatile(P2T_ATTN64_BODY_DIAG##N : P2T_ATTN64_OUTS, "={s[72:75]}"(cyc0), "={s[76:79]}"(cyc1) : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS_DIAG);
+            P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8)
 #undef P2T_ATTN64_DIAG
-        if (lane == 0) {
-            float* dst = lse + ((int64_t)id * 4 + w) * 16;
-            const unsigned c[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
-            for (int i = 0; i < 8; ++i) dst[i] = (float)c[i];
-            dst[8] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_in);
-            dst[9] = (float)n_it;
-            // wall clock (100 MHz) at entry / exit and where the block ran: the gaps between the blocks of one CU and the clock it held
-            const long long r_out = __builtin_amdgcn_s_memrealtime();
-            dst[10] = (float)(unsigned)(r_in & 0xFFFFFF);
-            dst[11] = (float)(unsigned)(r_out & 0xFFFFFF);
-            dst[12] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);          // HW_ID (wave / simd / cu / sh / se ...)
-            dst[13] = (float)__builtin_amdgcn_s_getreg((31 << 11) | 20);                      // XCC_ID
-        }
-    } else
+        } else
 #endif
-    if constexpr (CAUSAL)
-        asm volatile(P2T_ATTN64_BODY_1 : P2T_ATTN64_OUTS : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS);
-    else
-        asm volatile(P2T_ATTN64_BODY_0 : P2T_ATTN64_OUTS : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS);
+        if constexpr (CAUSAL)
+            asm volatile(P2T_ATTN64_BODY_1 : P2T_ATTN64_OUTS : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS);
+        else
+            asm volatile(P2T_ATTN64_BODY_0 : P2T_ATTN64_OUTS : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS);
 #undef P2T_ATTN64_OUTS
 #undef P2T_ATTN64_INS
-
-    // ---- epilogue: O^T rows = channels (r & 3) + 8 (r >> 2) + 4 hh (+ 32 per d-tile), column = query ----
-    char* stage = smem + kA64Ring + w * 8192;                 // [64 queries][128 B], 16-byte chunk c of row r at c ^ (r & 7)
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const float l = x == 0 ? lA : lB;
-        const float m = mref[x];
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
-        const int query = q0 + 32 * x + lq;
-        if (DIAG == 0 && lse && hh == 0 && query < seq) lse[(int64_t)(b * nh + h) * seq + query] = l > 0.f ? kLn2 * (m + __log2f(l)) : INFINITY;
-        const int row = 32 * x + lq;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const f32x16& o = x == 0 ? (dt == 0 ? oA0 : oA1) : (dt == 0 ? oB0 : oB1);
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int c16 = dt * 4 + rg;
-                *reinterpret_cast<uint2*>(stage + row * 128 + ((c16 ^ (row & 7)) << 4) + 8 * hh) =
-                    make_uint2(pack_bf16x2(o[4 * rg] * inv, o[4 * rg + 1] * inv), pack_bf16x2(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv));
+        const A64Block done = cur;
+        const int next = id + (int)gridDim.x;
+        if (next < n_blocks) {
+            cur = a64_block<CAUSAL>(next, q, k, v, key_mask, kv_info, B, seq, nh, nkv, w, lane);
+            __builtin_amdgcn_s_barrier();          // every wave is done with this block's K / V ring
+            P2T_ATTN64_RUN_PRE(cur);
+        }
+#ifdef P2T_LAB
+        if constexpr (DIAG != 0) {
+            if (lane == 0) {
+                float* dst = lse + ((int64_t)id * 4 + w) * 16;
+                for (int i = 0; i < 4; ++i) { dst[i] = (float)(unsigned)cyc0[i]; dst[4 + i] = (float)(unsigned)cyc1[i]; }
+                dst[8] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_in);
+                dst[9] = (float)done.n_it;
+                // wall clock (100 MHz) at entry / exit and where the block ran: the gaps between the blocks of one CU and the clock it held
+                const long long r_out = __builtin_amdgcn_s_memrealtime();
+                dst[10] = (float)(unsigned)(r_in & 0xFFFFFF);
+                dst[11] = (float)(unsigned)(r_out & 0xFFFFFF);
+                dst[12] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);          // HW_ID (wave / simd / cu / sh / se ...)
+                dst[13] = (float)__builtin_amdgcn_s_getreg((31 << 11) | 20);                      // XCC_ID
             }
         }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the stage is private to the wave: program order + this wait is enough
-    const int c = lane & 7;
+#endif
+        // ---- epilogue: O^T rows = channels (r & 3) + 8 (r >> 2) + 4 hh (+ 32 per d-tile), column = query ----
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + (lane >> 3), query = q0 + row;
-        const uint4 val = *reinterpret_cast<const uint4*>(stage + row * 128 + ((c ^ (row & 7)) << 4));
-        if (query < seq) {
-            bf16_t* orow = out + ((int64_t)b * seq + query) * ld_out;
-            if (c * 8 < d) *reinterpret_cast<uint4*>(orow + h * d + c * 8) = val;
-            if (h == nh - 1)
-                for (int cc = nh * d + c * 8; cc < out_cols; cc += 64) *reinterpret_cast<uint4*>(orow + cc) = make_uint4(0, 0, 0, 0);
+        for (int x = 0; x < 2; ++x) {
+            const float l = x == 0 ? lA : lB;
+            const float m = mref[x];
+            const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
+            const int query = done.q0 + 32 * x + lq;
+            if (DIAG == 0 && lse && hh == 0 && query < seq)
+                lse[(int64_t)(done.b * nh + done.h) * seq + query] = l > 0.f ? kLn2 * (m + __log2f(l)) : INFINITY;
+            const int row = 32 * x + lq;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const f32x16& o = x == 0 ? (dt == 0 ? oA0 : oA1) : (dt == 0 ? oB0 : oB1);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c16 = dt * 4 + rg;
+                    *reinterpret_cast<uint2*>(stage + row * 128 + ((c16 ^ (row & 7)) << 4) + 8 * hh) =
+                        make_uint2(pack_bf16x2(o[4 * rg] * inv, o[4 * rg + 1] * inv), pack_bf16x2(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv));
+                }
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the stage is private to the wave: program order + this wait is enough
+        const int c = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + (lane >> 3), query = done.q0 + row;
+            const uint4 val = *reinterpret_cast<const uint4*>(stage + row * 128 + ((c ^ (row & 7)) << 4));
+            if (query < seq) {
+                bf16_t* orow = out + ((int64_t)done.b * seq + query) * ld_out;
+                if (c * 8 < d) *reinterpret_cast<uint4*>(orow + done.h * d + c * 8) = val;
+                if (done.h == nh - 1)
+                    for (int cc = nh * d + c * 8; cc < out_cols; cc += 64) *reinterpret_cast<uint4*>(orow + cc) = make_uint4(0, 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the stage is read out before the next block's epilogue rewrites it
+        if (next >= n_blocks) break;
+        id = next;
     }
-    }       // persistent loop
+#undef P2T_ATTN64_RUN_PRE
 }
 
 bool attn_fwd64_eligible(int64_t ld_out, int T, int nh, int nkv, int d, int dp, int log2_scores) {

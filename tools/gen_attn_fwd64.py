@@ -75,7 +75,7 @@ NIT, LDSK, SEQ, FLAGS = 44, 45, 46, 47          # FLAGS: bit0 = last tile partia
 LDSV, Q0, TAILT, NITM1 = 48, 49, 50, 51
 J, R, TK, TV, J1, SLK, SLKS, MFROM, TMP, TMP2, KB = 52, 53, 54, 55, 56, 57, 58, 59, 61, 62, 63
 VIS, CC, RET = 66, 68, 84                       # pairs
-ACC0, PREV, CUR = 70, 78, 80                    # diagnostic build: s70..77 cycle sums per phase, s78 previous stamp, s[80:81] s_memtime
+ACC0, PREV, CUR = 72, 80, 82                    # diagnostic build: s72..79 cycle sums per phase, s80 previous stamp, s[82:83] s_memtime
 MAXS = 85
 
 # knobs of the diagnostic variants (lab build): the product uses the defaults
@@ -440,6 +440,58 @@ def iteration(c, end_label):
     e(f"s_cbranch_scc1 {end_label}")
 
 
+def tile_dma(kind, tile):
+    """Prologue form of one tile's two pieces (slot = tile & 3), skipped past the last tile."""
+    ptr, base, dv = (KPTR, LDSK, DVK) if kind == "K" else (VPTR, LDSV, DVV)
+    skip = lab("nopro")
+    e(f"s_cmp_le_u32 {sr(NIT)}, {tile}")
+    e(f"s_cbranch_scc1 {skip}")
+    e(f"s_cmp_eq_u32 {sr(TAILT)}, {tile}")
+    call("s_cbranch_scc1", SUBS["tail" + kind])
+    for p in range(2):
+        e(f"s_add_u32 m0, {sr(base)}, {(tile & 3) * SLOT + p * 4096}")
+        e("s_nop 0")
+        e(f"global_load_lds_dwordx4 {vr(dv + p)}, {sr(ptr, 2)}")
+    e(f"{skip}:")
+    e(f"s_add_u32 {sr(ptr)}, {sr(ptr)}, {SLOT}")
+    e(f"s_addc_u32 {sr(ptr + 1)}, {sr(ptr + 1)}, 0")
+
+
+def pre_body():
+    """The PRE statement: a block's Q fragments and its first six K / V tiles are requested BEFORE the previous block's epilogue
+    runs, so their flight is hidden under it (and, for the first block, under the index arithmetic of the kernel's entry).
+    Leaves: Q in a[64:95] (in flight), the DMA offsets in use in v146..149, KPTR / VPTR advanced past the tiles issued."""
+    del L[:]
+    del TAIL[:]
+    for k in ("tailK", "tailV"):
+        SUBS[k] = lab(k)
+    done = lab("predone")
+    e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
+    e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
+    for i in range(2):
+        e(f"v_mov_b32 {vr(DVK + i)}, {vr(VOFF + i)}")
+        e(f"v_mov_b32 {vr(DVV + i)}, {vr(VOFF + i)}")
+    # Q fragments first (vmcnt completes in order: any wait that covers a K/V piece covers them)
+    for X in "AB":
+        for kk in range(4):
+            e(f"global_load_dwordx4 {ar(Q[X] + 4 * kk, 4)}, {vr(QOFF[X])}, {sr(QPTR, 2)} offset:{32 * kk}")
+    # K0 K1 | V0 K2 | V1 K3
+    for kind, tile in (("K", 0), ("K", 1), ("V", 0), ("K", 2), ("V", 1), ("K", 3)):
+        tile_dma(kind, tile)
+    e(f"s_branch {done}")
+    sub_tail(SUBS["tailK"], DVK)
+    sub_tail(SUBS["tailV"], DVV)
+    for x in TAIL:
+        e(x)
+    e(f"{done}:")
+    return list(L)
+
+
+def zero16(reg, agpr):
+    z = vr(T[0], 4)
+    return f"v_mfma_f32_32x32x16_bf16 {ar(reg, 16) if agpr else vr(reg, 16)}, {z}, {z}, 0"
+
+
 def prologue(causal):
     fin0 = lab("fin0")
     if DIAG[0]:
@@ -451,48 +503,27 @@ def prologue(causal):
     e(f"s_sub_u32 {sr(NITM1)}, {sr(NIT)}, 1")
     e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
     e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
-    for i in range(2):
-        e(f"v_mov_b32 {vr(DVK + i)}, {vr(VOFF + i)}")
-        e(f"v_mov_b32 {vr(DVV + i)}, {vr(VOFF + i)}")
-    # Q fragments first (vmcnt completes in order: any wait that covers a K/V piece covers them)
+    # lane constants
+    e(f"v_mbcnt_lo_u32_b32 {vr(LANE)}, -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 {vr(LANE)}, -1, {vr(LANE)}")
+    e(f"v_lshrrev_b32 {vr(HH8)}, 5, {vr(LANE)}")
+    e(f"v_lshlrev_b32 {vr(HH8)}, 3, {vr(HH8)}")
+    # zeroed state: the matrix pipe writes 16 registers per instruction (0 x 0 + 0)
+    for i in range(4):
+        e(f"v_mov_b32 {vr(T[0] + i)}, 0")
+    e("s_nop 1")
     for X in "AB":
-        for kk in range(4):
-            e(f"global_load_dwordx4 {ar(Q[X] + 4 * kk, 4)}, {vr(QOFF[X])}, {sr(QPTR, 2)} offset:{32 * kk}")
-
-    # K0 K1 | V0 K2 | V1 K3   (slot = tile & 3)
-    def tile_dma(kind, tile):
-        ptr, base, dv = (KPTR, LDSK, DVK) if kind == "K" else (VPTR, LDSV, DVV)
-        skip = lab("nopro")
-        e(f"s_cmp_le_u32 {sr(NIT)}, {tile}")
-        e(f"s_cbranch_scc1 {skip}")
-        e(f"s_cmp_eq_u32 {sr(TAILT)}, {tile}")
-        call("s_cbranch_scc1", SUBS["tail" + kind])
-        for p in range(2):
-            e(f"s_add_u32 m0, {sr(base)}, {(tile & 3) * SLOT + p * 4096}")
-            e("s_nop 0")
-            e(f"global_load_lds_dwordx4 {vr(dv + p)}, {sr(ptr, 2)}")
-        e(f"{skip}:")
-        e(f"s_add_u32 {sr(ptr)}, {sr(ptr)}, {SLOT}")
-        e(f"s_addc_u32 {sr(ptr + 1)}, {sr(ptr + 1)}, 0")
-    for kind, tile in (("K", 0), ("K", 1), ("V", 0), ("K", 2), ("V", 1), ("K", 3)):
-        tile_dma(kind, tile)
-    # zeroed state, under the flight of the first tiles
+        e(zero16(NEGM[X], False))
+    e(zero16(P["B"], False))
     for X in "AB":
         for dt in range(2):
-            for r in range(16):
-                e(f"v_accvgpr_write_b32 {ar(O[X][dt] + r)}, 0")
-        for r in range(16):
-            e(f"v_accvgpr_write_b32 {ar(LACC[X] + r)}, 0")
-        for i in range(16):
-            e(f"v_mov_b32 {vr(NEGM[X] + i)}, 0")
+            e(zero16(O[X][dt], True))
+        e(zero16(LACC[X], True))
+    e(zero16(VF(1, 0, 0), True))
+    e(zero16(VF(1, 1, 0), True))
+    for X in "AB":
         e(f"v_mov_b32 {vr(MREF[X])}, 0")
         e(f"v_mov_b32 {vr(SEEN[X])}, 0")
-    for i in range(16):
-        e(f"v_mov_b32 {vr(P['B'] + i)}, 0")
-    for dt in range(2):
-        for ss in range(4):
-            for r in range(4):
-                e(f"v_accvgpr_write_b32 {ar(VF(1, dt, ss) + r)}, 0")
     for i in range(4):
         e(f"v_mov_b32 {vr(ONEV + i)}, {ONES}")
     # lazy-rescale threshold: 8 (log2 units); -inf on the first tile and for non-prefix masks.  Tiles from MFROM on hold hidden keys.
@@ -509,6 +540,7 @@ def prologue(causal):
         e(f"s_min_u32 {sr(MFROM)}, {sr(MFROM)}, {sr(TMP)}")
     e(f"s_cmp_eq_u32 {sr(NIT)}, 0")
     e(f"s_cbranch_scc1 {fin0}")
+    # the PRE statement issued Q, K0 K1 | V0 K2 | V1 K3; behind K1 at most 8 pieces (and the previous block's stores) are in flight
     w8, wb = lab("pw8"), lab("pwb")
     e(f"s_cmp_ge_u32 {sr(NIT)}, 4")
     e(f"s_cbranch_scc1 {w8}")
@@ -577,10 +609,10 @@ def body(causal, diag=False):
 
 
 def clobbers():
-    pinned_v = set(range(KA, KA + 4)) | set(range(VA, VA + 4)) | set(range(VOFF, VOFF + 4)) | set(range(154, 160)) | {132, 133}
+    pinned_v = set(range(KA, KA + 4)) | set(range(VA, VA + 4)) | set(range(DVK, DVK + 4)) | set(range(VOFF, VOFF + 4)) | set(range(154, 158)) | {132, 133}
     out = [f"v{i}" for i in range(MAXV + 1) if i not in pinned_v]
-    out += [f"a{i}" for i in range(64, 256) if i not in (LACC["A"], LACC["B"])]
-    out += [f"s{i}" for i in range(MAXS + 1) if (i >= 52 and not 70 <= i <= 81) or i in (TAILT, NITM1, LDSV)]
+    out += [f"a{i}" for i in range(96, 256) if i not in (LACC["A"], LACC["B"])]
+    out += [f"s{i}" for i in range(MAXS + 1) if (i >= 52 and not 72 <= i <= 83) or i in (TAILT, NITM1, LDSV)]
     out += ["vcc", "scc", "memory"]
     return out
 
@@ -609,6 +641,8 @@ def main():
         n_mfma = sum(1 for s in lines if s.startswith("v_mfma"))
         print(f"causal={causal}: {len(lines)} lines, {n_mfma} MFMAs")
     parts.append("#define P2T_ATTN64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    parts.append(emit_macro("P2T_ATTN64_PRE", pre_body()))
+    parts.append('#define P2T_ATTN64_PRE_CLOBBERS "s48", "s50", "s54", "s61", "s84", "s85", "vcc", "scc", "memory"\n')
     # diagnostic builds (lab library only): per-phase cycle sums in s70..s77, returned as outputs; variants 2.. are ablations
     # (their results are wrong by construction: what they measure is what the removed part costs)
     parts.append("#ifdef P2T_LAB\n")
@@ -618,7 +652,7 @@ def main():
         VAR.update(over)
         parts.append(emit_macro(f"P2T_ATTN64_BODY_DIAG{k + 1}", body(0, diag=True)))
     VAR.update(base)
-    parts.append("#define P2T_ATTN64_CLOBBERS_DIAG P2T_ATTN64_CLOBBERS, \"s78\", \"s80\", \"s81\"\n#endif\n")
+    parts.append("#define P2T_ATTN64_CLOBBERS_DIAG P2T_ATTN64_CLOBBERS, \"s80\", \"s82\", \"s83\"\n#endif\n")
     with open(OUT, "w") as f:
         f.write("\n".join(parts))
 
