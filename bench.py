@@ -482,6 +482,49 @@ def main():
             tf64 = f["total"] * 64 / dt64 / 1e12
             out["config"]["batch64_check"] = {"samples_per_s": round(64 / dt64, 2), "ms_per_step": round(dt64 * 1e3, 2),
                                               "step_tflops": round(tf64, 1), "frac_of_bf16_peak": round(tf64 / PEAK_BF16_TFLOPS, 4)}
+        if world == 1 and not args.no_batch64_check and args.config in ("cfg3", "cfg4"):
+            # BASELINE.json configs[4]'s one-GPU share (the same models with fp8-e4m3 tower GEMMs, batch 64 x 1024 residues) on the
+            # model already built: driver-visible beside the bf16 headline.  Outside the timed region;
+            # 1 settling step, then 3 timed on two streams, then 2 single-stream steps with every fp8 GEMM launch bracketed by HIP
+            # events (class 2: the same accounting as the roofline block of a `--config cfg5` run).
+            try:
+                model.set_gemm_dtype("fp8")
+                t5 = P.ContrastiveTrainer(model, num_segments=args.segments, train_mode=not args.eval_mode, global_negatives=True, overlap_streams=overlap)
+                if "b64" not in locals():
+                    pid64, pm64 = synth.protein_batch(99, 64, Tp)
+                    tid64, tm64 = synth.text_batch(99, 64, Tt)
+                    b64 = {k: torch.from_numpy(v).to(dev) for k, v in dict(protein_input_ids=pid64, protein_attention_mask=pm64,
+                                                                             description_input_ids=tid64, description_attention_mask=tm64).items()}
+                t5.step(b64)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    l5 = t5.step(b64)
+                torch.cuda.synchronize()
+                dt5 = (time.perf_counter() - t1) / 3
+                t5.overlap_streams = False
+                t5.step(b64)
+                torch.cuda.synchronize()
+                ms5, cnt5, fl5 = (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)(), (ctypes.c_double * 3)()
+                _lib.call("p2t_prof_enable", 1)
+                for _ in range(2):
+                    t5.step(b64)
+                torch.cuda.synchronize()
+                _lib.call("p2t_prof_collect", ms5, cnt5, fl5, 3)
+                _lib.call("p2t_prof_enable", 0)
+                tf5 = f["total"] * 64 / dt5 / 1e12
+                g5 = fl5[2] / max(ms5[2], 1e-9) / 1e9
+                out["config"]["cfg5_check"] = {"workload": "cfg5 share of one GPU: the same models, fp8-e4m3 tower GEMMs (per-row E8M0 scales), batch 64 x 1024 residues",
+                                               "samples_per_s": round(64 / dt5, 2), "ms_per_step": round(dt5 * 1e3, 2), "step_tflops": round(tf5, 1),
+                                               "step_frac_of_fp8_peak": round(tf5 / PEAK_FP8_TFLOPS, 4), "fp8_gemm_tflops": round(g5, 1),
+                                               "fp8_gemm_frac_of_fp8_peak": round(g5 / PEAK_FP8_TFLOPS, 4), "fp8_gemm_launches_per_step": cnt5[2] // 2,
+                                               "fp8_gemm_avg_launch_ms": round(ms5[2] / max(cnt5[2], 1), 4), "attention_ms_per_step": round(ms5[1] / 2, 3),
+                                               "loss": round(float(l5.cpu()[0]), 5)}
+                del t5
+            except Exception as e:                                      # noqa: BLE001
+                out["config"]["cfg5_check"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                model.set_gemm_dtype("model")
         if world == 1 and not args.no_batch64_check and args.config in ("cfg3", "cfg4", "cfg5"):
             # Ragged workload: 64 pairs with protein lengths from a clipped log-normal (median ~315
             # residues, the shape of UniProt lengths; crop at 1024), once as the padded 64 x T_max step and once

@@ -334,6 +334,24 @@ int p2t_cross_entropy_shifted_backward(const void* logits, int64_t ld, int dtype
 int p2t_rmsnorm_backward(const float* x, int64_t ld_x, const float* w, float eps, const void* dy, int64_t ld_dy,
                          int dy_dtype, float* dx, int64_t ld_dx, int64_t rows, int64_t cols, int accumulate,
                          p2t_stream stream);
+/* Pieces of the stage-2 step exposed one by one, for the LoRA form of that step (scripts/train_instruct.py:146-183; p2t_hip/
+ * decoder_train.py drives them per layer -- the low-rank branches sit BETWEEN the fused blocks of p2t_llama_train_forward):
+ * SwiGLU on the interleaved gate / up pre-activations of p2t_llama_layer.gu_w (64-column block j = gate[32 j..] | up[32 j..]):
+ * d_act == NULL: out[m, f] = silu(g) u (out `dtype` [M, ld_out >= F], zeros up to the next multiple of 64);
+ * else the backward: out = d_gu in the same interleaved layout [M, 2F] from d_act [M, ld_da]. */
+int p2t_swiglu_gu(const void* gu, int64_t ld_gu, const void* d_act, int64_t ld_da, void* out, int64_t ld_out, int64_t M, int64_t F,
+                  int dtype, p2t_stream stream);
+/* Backward of the head split + rotation (+ q_scale folded into q) of p2t_qkv_post: dq [B, nh, T, dp], dk, dv [B, nkv, T, dp] f32
+ * -> d_qkv `dtype` [B*T, ld], rows = [q heads | k heads | v heads] in the natural order of q_proj / k_proj / v_proj.
+ * cos_sin_scratch f32 [T * d]. */
+int p2t_rope_backward_pack(const float* dq, const float* dk, const float* dv, const float* inv_freq, float* cos_sin_scratch,
+                           void* d_qkv, int64_t ld, int B, int T, int nh, int nkv, int d, int dp, float q_scale, int dtype,
+                           p2t_stream stream);
+/* dst[m, c] (+)= keep(seed, m K + c) ? src[m, c] / (1 - p) : 0, c < K (F32 / BF16 either side): the input dropout of a LoRA
+ * branch (`lora_dropout`) and, called again with the same seed on the gradient, its backward -- the mask is the counter-hash
+ * of (seed, element), regenerated, never stored.  p == 0: a (converting, optionally accumulating) copy. */
+int p2t_dropout_rows(const void* src, int src_dtype, int64_t ld_src, void* dst, int dst_dtype, int64_t ld_dst, int64_t M,
+                     int64_t K, float p, uint64_t seed, int accumulate, p2t_stream stream);
 /* dst[dst_pos[r], :H] = src[src_pos[r], :H], r < min(*n_dst, *n_src), f32: the backward of p2t_scatter_rows (the
  * gradient of `inputs_embeds[placeholder_mask] = encoder_hidden_states[encoder_mask]` with respect to the encoder
  * states: call it with the two position lists swapped; rows not listed keep their contents -- zero dst first). */

@@ -122,7 +122,10 @@ int attention(const void* q, const void* k, const void* v, const uint8_t* key_ma
     if (dtype == P2T_BF16 && use_mfma != 0) {
         const int pi = prof_begin(s, 1, 4.0 * B * nh * (double)T * T * d * (causal ? 0.5 : 1.0));
         // use_mfma: 2 = the general kernel (attn_mfma.hip) even where the hand-placed one applies; 3 = require the hand-placed one
-        const bool hand = use_mfma != 2 && attn_fwd64_eligible(ld_out, T, nh, nkv, d, dp, log2_scores);
+        // (a forward that also returns the log-sum-exps -- the stage-2 training forward -- stays on the general kernel unless the
+        // hand-placed one is asked for: its row sums are taken over the bf16-rounded probabilities, 3e-4 off the fp32 sums the exact
+        // backward rebuilds P from; the frozen towers of the contrastive step never ask for them)
+        const bool hand = use_mfma != 2 && (lse == nullptr || use_mfma == 3) && attn_fwd64_eligible(ld_out, T, nh, nkv, d, dp, log2_scores);
         if (use_mfma == 3 && !hand) {
             set_error("attention: the hand-placed kernel needs head_dim padded to 64, d %% 8 == 0 and log2_scores (d=%d dp=%d)", d, dp);
             return P2T_ERR_UNSUPPORTED;

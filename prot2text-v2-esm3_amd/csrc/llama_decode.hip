@@ -765,6 +765,10 @@ extern "C" int p2t_llama_decode_step(const p2t_llama_config* c, const p2t_llama_
         P2T_TRY(gemm_nt(g4, s, stream_w ? ws_layers[l].down_w : nullptr));
     }
     P2T_REQUIRE(!lm_head_preshuffled || dt == P2T_BF16, "p2t_llama_decode_step: pre-shuffled weights are a bf16 layout");
+    // the stream-order copy is only readable by the skinny kernels (<= 64 rows): beyond that the general GEMM would read the
+    // shuffled tiles as a row-major [vocab, Hp] matrix and return wrong logits without an error
+    P2T_REQUIRE(!lm_head_preshuffled || M <= 64, "p2t_llama_decode_step: a pre-shuffled LM head serves at most 64 rows (got %lld): pass the row-major one",
+                (long long)M);
     P2T_TRY(launch_rmsnorm_few_rows(b.x, H, w->final_norm_w, c->rms_norm_eps, b.h, Hp, M, H, dt, s));
     GemmArgs gh{b.h, Hp, lm_head, ld_head, nullptr, logits, ld_logits, nullptr, M, c->vocab, Hp, dt, dt, P2T_EPI_STORE, 0, -1, -1, 0.f, 0, 0};
     P2T_TRY(gemm_nt(gh, s, lm_head_preshuffled ? lm_head : nullptr));

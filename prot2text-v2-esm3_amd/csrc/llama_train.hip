@@ -10,6 +10,7 @@
 //   x1 = x  + o(attn(rope(q(h1)), rope(k(h1)), v(h1))), h1 = rmsnorm(x) -> attn_bwd_{dq,dkv}, rope_bwd_pack, rmsnorm_bwd
 // The residual-stream gradient stays fp32 throughout (one buffer, accumulated in place); GEMM operands are `dtype`.
 #include "common.h"
+#include "epilogue.h"
 #include "kernels.h"
 
 namespace p2t {
@@ -605,6 +606,59 @@ extern "C" int p2t_cross_entropy_shifted_backward(const void* logits, int64_t ld
                                                                                 (float*)d_logits, ld_d, cols_d);
     P2T_LAUNCH_CHECK();
     return P2T_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dst (+)= keep(seed, m * K + c) ? src / (1 - p) : 0: the LoRA branch's input dropout (peft lora_dropout, train_instruct.py:158) and,
+// with the same seed, its backward (the mask is regenerated, never stored).
+template <typename Ts, typename Td>
+__global__ void __launch_bounds__(256) dropout_rows_kernel(const Ts* __restrict__ src, int64_t ld_src, Td* __restrict__ dst, int64_t ld_dst, int64_t M,
+                                                           int K, float p, float scale, uint64_t seed, int accumulate) {
+    const int64_t n = M * (int64_t)K, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t m = i / K;
+        const int c = (int)(i - m * K);
+        float x = to_f32(src[m * ld_src + c]);
+        x = (p > 0.f && !dropout_keep(seed, i, p)) ? 0.f : x * scale;
+        Td* d = dst + m * ld_dst + c;
+        *d = from_f32<Td>(accumulate ? to_f32(*d) + x : x);
+    }
+}
+
+extern "C" int p2t_dropout_rows(const void* src, int src_dtype, int64_t ld_src, void* dst, int dst_dtype, int64_t ld_dst, int64_t M, int64_t K, float p,
+                                uint64_t seed, int accumulate, p2t_stream stream) {
+    P2T_REQUIRE(src && dst && M >= 0 && K > 0 && ld_src >= K && ld_dst >= K && p >= 0.f && p < 1.f, "p2t_dropout_rows: bad arguments");
+    if (M == 0) return P2T_OK;
+    const float scale = 1.0f / (1.0f - p);
+    const int64_t n = M * K;
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 8192 ? ceil_div(n, 256) : 8192);
+    hipStream_t s = (hipStream_t)stream;
+#define P2T_DROP(TS, TD) dropout_rows_kernel<TS, TD><<<grid, 256, 0, s>>>((const TS*)src, ld_src, (TD*)dst, ld_dst, M, (int)K, p, scale, seed, accumulate)
+    if (src_dtype == P2T_BF16 && dst_dtype == P2T_BF16) P2T_DROP(bf16_t, bf16_t);
+    else if (src_dtype == P2T_F32 && dst_dtype == P2T_BF16) P2T_DROP(float, bf16_t);
+    else if (src_dtype == P2T_BF16 && dst_dtype == P2T_F32) P2T_DROP(bf16_t, float);
+    else if (src_dtype == P2T_F32 && dst_dtype == P2T_F32) P2T_DROP(float, float);
+    else { set_error("p2t_dropout_rows: unsupported dtypes %d -> %d", src_dtype, dst_dtype); return P2T_ERR_ARG; }
+#undef P2T_DROP
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+
+extern "C" int p2t_swiglu_gu(const void* gu, int64_t ld_gu, const void* d_act, int64_t ld_da, void* out, int64_t ld_out, int64_t M, int64_t F, int dtype,
+                             p2t_stream stream) {
+    P2T_REQUIRE(gu && out && M >= 0 && F > 0 && (dtype == P2T_F32 || dtype == P2T_BF16), "p2t_swiglu_gu: bad arguments");
+    if (M == 0) return P2T_OK;
+    if (d_act) return launch_swiglu_gu<true>(gu, ld_gu, d_act, ld_da, out, ld_out, M, F, dtype, (hipStream_t)stream);
+    return launch_swiglu_gu<false>(gu, ld_gu, nullptr, 0, out, ld_out, M, F, dtype, (hipStream_t)stream);
+}
+
+extern "C" int p2t_rope_backward_pack(const float* dq, const float* dk, const float* dv, const float* inv_freq, float* cos_sin_scratch, void* d_qkv,
+                                      int64_t ld, int B, int T, int nh, int nkv, int d, int dp, float q_scale, int dtype, p2t_stream stream) {
+    P2T_REQUIRE(dq && dk && dv && inv_freq && cos_sin_scratch && d_qkv && B > 0 && T > 0 && ld >= (int64_t)(nh + 2 * nkv) * d,
+                "p2t_rope_backward_pack: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    P2T_TRY(launch_rope_table(inv_freq, T, d / 2, cos_sin_scratch, s));
+    return launch_rope_bwd_pack(dq, dk, dv, cos_sin_scratch, d_qkv, ld, B, T, nh, nkv, d, dp, q_scale, dtype, s);
 }
 
 extern "C" int p2t_gather_rows_f32(float* dst, int64_t ld_dst, const int32_t* dst_pos, const float* src, int64_t ld_src, const int32_t* src_pos,

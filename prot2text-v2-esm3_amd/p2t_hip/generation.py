@@ -88,7 +88,8 @@ def stream_weights(decoder):
     m, s = decoder.model, decoder.spec
     e = m.ensure_engine(s.num_hidden_layers)
     lm = decoder._lm_head_padded()
-    key = (id(e), lm.data_ptr(), bool(m.gemm_fp8))
+    # (the engine object is rebuilt when weights are loaded; _version catches an in-place update of the LM head that kept the engine)
+    key = (id(e), lm.data_ptr(), lm._version, decoder.model.embed_tokens.weight._version, bool(m.gemm_fp8))
     st = getattr(m, "_stream_engine", None)
     if st is not None and st["key"] == key:
         return st
@@ -135,7 +136,9 @@ class DecodeEngine:
         self.ws = torch.empty((call("p2t_llama_decode_workspace_bytes", C.byref(self.e["cfg"]), self.BB, self.Tp, self.G),), dtype=torch.uint8,
                               device=self.dev)
         self.lm_head = decoder._lm_head_padded()
-        self.stream = stream_weights(decoder) if (stream_copy and self.dtype == torch.bfloat16) else None
+        # the stream-order copies are read by the skinny GEMMs only (<= 64 rows): beyond that every projection and the LM head
+        # run on the row-major weights (the LM head had no row-major fallback and returned wrong logits)
+        self.stream = stream_weights(decoder) if (stream_copy and self.dtype == torch.bfloat16 and B0 * group <= 64) else None
         self._cache_struct()
 
     def _cache_struct(self):
@@ -264,6 +267,10 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
         logits = logits.repeat_interleave(R, dim=0)
     V = decoder.spec.vocab_size
     eos = torch.tensor(eos_ids, dtype=torch.int64, device=eng.dev)
+    if do_sample and return_dict_in_generate and output_scores:
+        # HF returns the PROCESSED scores (after temperature / top-k / top-p) under sampling; nothing here is pinned on that
+        # (the goldens cover greedy and beam search), so the combination is refused rather than answered with the raw logits
+        raise NotImplementedError("generate: output_scores with do_sample is not supported (ask for output_logits: the raw LM-head rows)")
     keep_logits = [] if (return_dict_in_generate and (output_logits or output_scores)) else None
     pad = int(pad_token_id)
 
@@ -295,7 +302,7 @@ def generate(decoder, inputs_embeds: Optional[torch.Tensor] = None, attention_ma
         if use_graph and not do_sample and n >= 2:        # the first step ran eagerly (lazy one-time initialisation inside the library)
             if graph is None:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     advance()
             graph.replay()
         else:

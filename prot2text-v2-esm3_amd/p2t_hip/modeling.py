@@ -733,6 +733,15 @@ class LlamaDecoder(nn.Module):
                 raise ValueError(f"labels shape {tuple(labels.shape)} != {(B, T)}")
             if attention_mask is None:
                 attention_mask = torch.ones((B, T), dtype=torch.int64, device=inputs_embeds.device)
+            if getattr(self, "gradient_checkpointing", False) and not getattr(self, "_warned_checkpointing", False):
+                # the caller asked for activation checkpointing (reference :253-268 forwards the flag to the decoder): the stage-2
+                # step keeps its whole activation tape (p2t_llama_tape_bytes: ~26 GB per 4 x 1216 tokens of Llama-3.1-8B) and
+                # recomputes nothing -- say so once instead of silently returning no memory
+                import warnings
+                warnings.warn("gradient checkpointing was requested, but the stage-2 step of this decoder keeps the full activation tape "
+                              f"({call('p2t_llama_tape_bytes', C.byref(m.ensure_engine(L)['cfg']), B, T) / 2 ** 30:.1f} GiB for this batch) and recomputes "
+                              "nothing: lower the micro-batch if memory is the limit", RuntimeWarning, stacklevel=2)
+                self._warned_checkpointing = True
             loss, logits = _DecoderLossFn.apply(inputs_embeds, self, attention_mask, labels)
             return CausalLMOutput(loss=loss, logits=logits[..., : s.vocab_size])
         h = m.hidden_state(input_ids, attention_mask, L) if inputs_embeds is None else m.hidden_state_from_embeds(inputs_embeds, attention_mask, L)
@@ -974,12 +983,15 @@ class Esm2LlamaInstructForCausalLM(PreTrainedModel):
         `gradient_checkpointing_kwargs`), and a no-op by construction: activation checkpointing trades recomputation for the
         memory autograd holds, and on this path the frozen towers run WITHOUT autograd (nothing is kept), while the adapter keeps
         one set of activations per segment (z1, h1, z2: ContrastiveTrainer._buffers) -- `contrastive_num_segments` bounds that,
-        as it does upstream."""
+        as it does upstream.  The stage-2 step (LM loss through the frozen decoder) is different: it keeps its whole activation
+        tape and recomputes nothing, and warns once when it runs under this flag."""
         self._gradient_checkpointing_requested = True
+        self.llama_decoder.gradient_checkpointing = True      # the stage-2 step warns once that its tape is kept whole (LlamaDecoder.forward)
 
     def gradient_checkpointing_disable(self):
         """No-op (reference :263-268)."""
         self._gradient_checkpointing_requested = False
+        self.llama_decoder.gradient_checkpointing = False
 
     @property
     def is_gradient_checkpointing(self) -> bool:

@@ -471,6 +471,93 @@ def run_sft_backward(ref):
                         meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
     print(f"wrote {path}")
 
+LORA_TARGETS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+
+class _LoraLinear(torch.nn.Module):
+    """What `peft.LoraConfig(r, lora_alpha=2r, lora_dropout=p, bias="none")` (scripts/train_instruct.py:155-176) makes of a target
+    nn.Linear: y = W x + (alpha / r) B (A drop(x)), W frozen, A [r, in] and B [out, r] trained.  `peft` is not importable here: this
+    is the published LoRA arithmetic on the reference class's own decoder, not peft's code -- parity against peft itself is unpinned."""
+
+    def __init__(self, base: torch.nn.Linear, r: int, alpha: float, a: np.ndarray, b: np.ndarray):
+        super().__init__()
+        self.base, self.scale = base, alpha / r
+        self.lora_A = torch.nn.Parameter(torch.from_numpy(a.copy()))
+        self.lora_B = torch.nn.Parameter(torch.from_numpy(b.copy()))
+
+    def forward(self, x):
+        return self.base(x) + self.scale * ((x @ self.lora_A.t()) @ self.lora_B.t())
+
+
+def lora_init(seed: int, layer: int, target: str, r: int, n_out: int, n_in: int):
+    """A and B of one target from the counter-hash generator (both non-zero: peft's B = 0 start would make every dA vanish)."""
+    from p2t_hip import synth
+    a = synth.uniform_f32(seed, f"lora.{layer}.{target}.A", (r, n_in), 0.25)
+    b = synth.uniform_f32(seed, f"lora.{layer}.{target}.B", (n_out, r), 0.25)
+    return a, b
+
+
+def run_sft_lora(ref):
+    """Stage-2 step WITH LoRA adapters on the seven decoder projections (scripts/train_instruct.py:146-183; r = 4, alpha = 2r,
+    dropout 0 for a deterministic target) and the modality adapter trainable (`modules_to_save`): torch autograd through the
+    reference class with every target wrapped by _LoraLinear.  Loss, gradient at the decoder inputs, the adapter's four gradients
+    and dA / dB of every (layer, target).  Also the Qwen3 decoder (per-head q / k RMSNorm) WITHOUT LoRA: its adapter gradients pin
+    the q / k-norm backward.  Decoder shapes as sft_grad_tiny."""
+    import json
+    r = 4
+    cases = {
+        "d16": (specs.LlamaSpec(num_hidden_layers=3, hidden_size=64, intermediate_size=160, num_attention_heads=4, num_key_value_heads=2, vocab_size=512), 64, True),
+        "d64": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=320, num_attention_heads=4, num_key_value_heads=2, vocab_size=512), 256, True),
+        "d128": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=256, intermediate_size=288, num_attention_heads=2, num_key_value_heads=1, vocab_size=512,
+                                 rope_type="default", rope_theta=10000.0), 256, True),
+        "qwen3": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=192, num_attention_heads=4, num_key_value_heads=2, vocab_size=512,
+                                  head_dim=48, qk_norm=True, rope_type="default", rope_theta=10000.0, tie_word_embeddings=False), 128, False),
+        "qwen3_lora": (specs.LlamaSpec(num_hidden_layers=2, hidden_size=128, intermediate_size=192, num_attention_heads=4, num_key_value_heads=2, vocab_size=512,
+                                       head_dim=48, qk_norm=True, rope_type="default", rope_theta=10000.0, tie_word_embeddings=False), 128, True),
+    }
+    out, metas = {}, {}
+    placeholder_id = 511
+    lens = [10, 6, 3]
+    pid, pmask, ids, mask, labels = sft_batch(3, lens, 18, 9, placeholder_id, 510, 500, 7)
+    t = lambda a: torch.from_numpy(a)
+    for name, (llama, H, lora) in cases.items():
+        esm = specs.EsmSpec(num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4)
+        ad = specs.AdapterSpec(64, 96, H, 0.3)
+        model = build_reference_model(ref, esm, llama, ad, 0)
+        model.config.placeholder_id = placeholder_id
+        model.adapter.requires_grad_(True)
+        wrapped = {}
+        if lora:
+            for i, layer in enumerate(model.llama_decoder.model.layers):
+                for tgt in LORA_TARGETS:
+                    parent, leaf = tgt.split(".")
+                    base = getattr(getattr(layer, parent), leaf)
+                    a, b = lora_init(5, i, tgt, r, base.out_features, base.in_features)
+                    w = _LoraLinear(base, r, 2.0 * r, a, b)
+                    setattr(getattr(layer, parent), leaf, w)
+                    wrapped[(i, tgt)] = w
+        emb, _ = model(input_ids=t(ids), attention_mask=t(mask), protein_input_ids=t(pid), protein_attention_mask=t(pmask),
+                       return_decoder_inputs=True)
+        emb.retain_grad()
+        res = model.llama_decoder(inputs_embeds=emb, attention_mask=t(mask), labels=t(labels))
+        res.loss.backward()
+        out[f"{name}.loss"] = np.float32(res.loss.item())
+        out[f"{name}.d_inputs_embeds"] = emb.grad.numpy().copy()
+        for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+            out[f"{name}.grad.{n}"] = dict(model.adapter.named_parameters())[n].grad.numpy().copy()
+        for (i, tgt), w in wrapped.items():
+            out[f"{name}.lora.{i}.{tgt}.dA"] = w.lora_A.grad.numpy().copy()
+            out[f"{name}.lora.{i}.{tgt}.dB"] = w.lora_B.grad.numpy().copy()
+        metas[name] = dict(esm=specs.spec_dict(esm), llama=specs.spec_dict(llama), adapter=specs.spec_dict(ad), lora=bool(lora))
+        gl = max((float(w.lora_A.grad.norm()) for w in wrapped.values()), default=0.0)
+        print(f"sft_lora {name}: loss {float(res.loss):.6f} |d emb| {float(emb.grad.norm()):.4e} |g fc2.w| {float(model.adapter.fc2.weight.grad.norm()):.4e} max |dA| {gl:.3e}")
+    meta = dict(cases=metas, placeholder_id=placeholder_id, lens=lens, r=r, alpha=2.0 * r, lora_seed=5, targets=list(LORA_TARGETS))
+    path = os.path.join(HERE, "sft_lora_tiny.npz")
+    np.savez_compressed(path, protein_input_ids=pid, protein_attention_mask=pmask, input_ids=ids, attention_mask=mask, labels=labels,
+                        meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
+    print(f"wrote {path}")
+
+
 def run_generate(ref):
     """`Esm2LlamaInstructForCausalLM.generate` of the reference (models/modeling_esm2llama_instruct.py:217-251) on tiny random-init
     towers, driven as scripts/generate_instruct.py:72-87 drives it: left-padded prompts holding protein placeholders, greedy decoding
@@ -555,7 +642,7 @@ def run_generate(ref):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft,sft_grad,generate")
+    ap.add_argument("--only", default="ops,tiny,tiny_d24,tiny_d128,tiny_d64,tiny_qwen3,cfg1,collate,train_state,sft,sft_grad,sft_lora,generate")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.manual_seed(0)
@@ -571,6 +658,8 @@ def main():
         run_sft(ref)
     if "sft_grad" in only:
         run_sft_backward(ref)
+    if "sft_lora" in only:
+        run_sft_lora(ref)
     if "generate" in only:
         run_generate(ref)
     if "tiny" in only:

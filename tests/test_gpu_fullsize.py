@@ -216,6 +216,38 @@ def test_cfg3_bf16_pipeline_vs_exact_fp32_pipeline(cfg3):
     observe("cfg3.bf16_vs_fp32pipeline.protein", rel(p16, p32), 5e-2)             # 36 layers of bf16 storage
 
 
+def test_cfg3_fp32_pipeline_vs_fp32_oracle_at_north_star_tolerance(cfg3):
+    """BASELINE.json north_star: "pooled embeddings, loss match the reference CPU path within 1e-3 relative fp32 tolerance" --
+    asserted HERE at configs[2]'s own size with an INLINE bound (no tolerance table): the fp32 HIP pipeline (full esm2_t36_3B +
+    16 layers of Llama-3.1-8B on the fp32-FMA kernels) against the fp32 oracle on the same fp32 weights, two ragged pairs
+    (1024 + 411 residues / 128 + 33 tokens).  The bf16 pipeline cannot meet 1e-3 (bf16 storage: DESIGN.md section 6 holds its
+    observed error and where it comes from); the fp32 path is what carries the claim at this size.
+    Reference arithmetic: scripts/train_contrast.py:284-310,345-379."""
+    from oracle import p2t_oracle as O
+    sys.path.insert(0, ROOT)
+    from bench import GpuWeights
+    P = cfg3["P"]
+    m32 = build_model(cfg3["esm"], cfg3["llama"], cfg3["ad"], torch.float32, 0).eval()
+    pid, pmask, tid, tmask = _cfg3_oracle_pairs(cfg3)
+    p, t, loss = _step_outputs(P, m32, _batch(pid, pmask, tid, tmask))
+    W = GpuWeights(m32, cache=True)
+    ps, ts = [], []
+    for i in range(pid.shape[0]):                       # every pair at its own length (padding changes nothing: tested above)
+        n_p, n_t = int(pmask[i].sum()), int(tmask[i].sum())
+        ps.append(O.protein_embeddings(cfg3["esm"], W, pid[i:i + 1, :n_p], pmask[i:i + 1, :n_p], "mix", False, O.FP32))
+        ts.append(O.text_embeddings(cfg3["llama"], W, tid[i:i + 1, :n_t], tmask[i:i + 1, :n_t], 16, "mix", O.FP32))
+    rp, rt = np.concatenate(ps, 0), np.concatenate(ts, 0)
+    rl = float(O.contrastive_loss(rp, rt, 1))
+    del W, m32
+    torch.cuda.empty_cache()
+    ep, et, el = rel(p, rp), rel(t, rt), abs(loss - rl) / max(1.0, abs(rl))
+    print(f"cfg3 fp32 HIP vs fp32 oracle: protein {ep:.2e} text {et:.2e} loss {el:.2e}")
+    observe("cfg3.fp32_vs_fp32oracle.protein", ep, 1e-3)
+    observe("cfg3.fp32_vs_fp32oracle.text", et, 1e-3)
+    observe("cfg3.fp32_vs_fp32oracle.loss", el, 1e-3, "abs/max(1,|ref|)")
+    assert ep < 1e-3 and et < 1e-3 and el < 1e-3, (ep, et, el)          # north_star's bound, whatever the table says
+
+
 def test_cfg3_batch_size_invariance_across_kernel_forms(cfg3):
     """The same sequences inside a large batch (persistent GEMM kernels: 16 x 1024 residues, 64 x 128 tokens) and inside a
     small one (per-tile kernels) give the same embeddings: rows never interact, whichever launch form computes them."""

@@ -450,3 +450,52 @@ def test_long_beam_search_reorders_more_than_one_tile_of_generated_keys(g):
     seq, sc = O.generate_beam(llama, W, to_np(emb), to_np(mask), n, 3, (m["eos"],), pad, 1.0)
     assert np.array_equal(to_np(out.sequences), seq) and seq.shape[1] > 64
     assert np.abs(to_np(out.sequences_scores) - sc).max() < 1e-4
+
+
+def test_more_than_64_rows_decode_on_the_row_major_weights(g):
+    """with the default stream copies a bf16 `generate` over more than 64 rows (prompts x beams) handed the
+    PRE-SHUFFLED LM head to the general GEMM, which read it as a row-major matrix: wrong tokens, no error.  72 greedy rows (the three
+    golden prompts tiled 24 times) must give, row for row, the tokens and logits of the same prompts in a 3-row call (rows never
+    interact); 16 prompts x 5 beams = 80 rows must score like the same prompts run four at a time (20 rows); and the C entry point refuses a
+    pre-shuffled LM head beyond 64 rows instead of mis-reading it."""
+    import ctypes as C
+    from p2t_hip import _lib, generation
+    case = "d64"
+    model = _model(g, case, torch.bfloat16)
+    meta = g["meta"]
+    pad, n = meta["pad_id"], 6
+    kw = _inputs(g)
+    small = model.generate(**kw, max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True, output_logits=True)
+    rep = 24
+    big_kw = {k: v.repeat(rep, *([1] * (v.dim() - 1))) for k, v in kw.items()}
+    big = model.generate(**big_kw, max_new_tokens=n, eos_token_id=None, pad_token_id=pad, do_sample=False, return_dict_in_generate=True, output_logits=True)
+    ts, tb = to_np(small.sequences), to_np(big.sequences)
+    assert tb.shape == (3 * rep, n)
+    ls, lb = to_np(torch.stack(small.logits, 0)), to_np(torch.stack(big.logits, 0))
+    for r in range(rep):
+        # the skinny kernels (3 rows) and the general GEMM (72 rows) sum in different orders: compare logits, and tokens where the top-2 gap is clear
+        assert rel(lb[:, 3 * r:3 * r + 3], ls) < 2e-2, r
+        top2 = np.sort(ls.astype(np.float64), axis=-1)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 0.05 * np.abs(top2[..., 1]).clip(1e-3)
+        assert np.array_equal(tb[3 * r:3 * r + 3].T[clear], ts.T[clear]), r
+    # beams: 16 prompts x 5 beams = 80 rows against the same prompts run 4 at a time (20 rows: the skinny kernels)
+    rep = 6
+    b_kw = {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:16] for k, v in kw.items()}
+    m = meta["cases"][case]
+    wide = model.generate(**b_kw, max_new_tokens=n, eos_token_id=m["eos"], pad_token_id=pad, do_sample=False, num_beams=5, return_dict_in_generate=True,
+                          output_scores=True)
+    for i in range(0, 16, 4):
+        part = {k: v[i:i + 4] for k, v in b_kw.items()}
+        narrow = model.generate(**part, max_new_tokens=n, eos_token_id=m["eos"], pad_token_id=pad, do_sample=False, num_beams=5,
+                                return_dict_in_generate=True, output_scores=True)
+        diff = np.abs(to_np(wide.sequences_scores)[i:i + 4] - to_np(narrow.sequences_scores))
+        assert np.isfinite(diff).all() and np.median(diff) < 5e-2 and diff.max() < 0.3, (i, diff)     # bf16 logits, two GEMM kernels: near-tied beams may swap
+    # the C boundary itself: a pre-shuffled LM head with 65 rows is an argument error
+    eng = generation.DecodeEngine(model.llama_decoder, 65, 1, 8, 8, stream_copy=True)
+    assert eng.stream is None                                              # the engine did not even build the copies
+    st = generation.stream_weights(model.llama_decoder)
+    layers = C.cast(st["layers"], C.POINTER(_lib.LlamaLayerStreamC))
+    from p2t_hip.ops import ptr, stream
+    with pytest.raises(Exception, match="at most 64 rows"):
+        _lib.call("p2t_llama_decode_step", C.byref(eng.e["cfg"]), C.byref(eng.e["w"]), layers, ptr(st["lm_head"]), eng.lm_head.stride(0), 1,
+                  C.byref(eng.cache), ptr(eng.x), ptr(eng.logits), eng.ld_logits, eng.flags, ptr(eng.ws), eng.ws.numel(), stream())

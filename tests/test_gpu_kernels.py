@@ -525,6 +525,56 @@ def test_gemm_four_wave_long_k_fuzz_vs_eight_wave_forms(ops, gemm_policy):
     assert _no_timeout()
 
 
+def test_attention_hand_placed_kernel_vs_exact_and_general(ops):
+    """csrc/attn_fwd64.hip (head_dim padded to 64, log2-scores q; the kernel bench.py's ESM2 towers run) against the exact
+    fp32-softmax kernel and the general MFMA kernel on the same bf16 operands: ragged / causal / GQA / non-prefix masks, sequence
+    lengths on both sides of the 64-key tile and 256-query block boundaries, one to many blocks per workgroup (the kernel is
+    persistent), padded head dims, the pad columns of the last head, and the log-sum-exp output the backward reads."""
+    rng = np.random.default_rng(23)
+    L2E = 1.4426950408889634
+    shapes = [(1, 64, 1, 1, 64), (1, 65, 2, 1, 64), (2, 256, 2, 2, 64), (2, 257, 3, 3, 40), (1, 1, 2, 2, 64), (3, 130, 8, 8, 40), (2, 700, 4, 1, 64),
+              (2, 1024, 5, 5, 64), (40, 300, 8, 2, 64), (1, 2048, 2, 2, 64), (2, 511, 3, 1, 48)]
+    for it, (B, T, nh, nkv, d) in enumerate(shapes):
+        for causal in (False, True):
+            lens = [T if b == 0 else int(rng.integers(1, T + 1)) for b in range(B)]
+            mask = np.zeros((B, T), dtype=np.int64)
+            for b, n in enumerate(lens):
+                mask[b, :n] = 1
+            non_prefix = it % 4 == 3 and not causal
+            if non_prefix:
+                mask = (rng.random((B, T)) < 0.6).astype(np.int64)
+                mask[:, 0] = 0
+                mask[:, T // 2] = 1
+            qkv = to_dev(bf16r(rnd(60 + it, "ah.qkv", (B * T, (nh + 2 * nkv) * d), float(rng.choice([0.5, 1.5, 4.0])))), torch.bfloat16)
+            inv = to_dev(O.default_inv_freq(10000.0, d))
+            key_mask, kv_info, _ = ops.mask_prepare(to_dev(mask))
+            q, k, v = ops.qkv_post(qkv, inv, B, T, nh, nkv, d, float(d) ** -0.5 * L2E)
+            lse = [torch.zeros((B, nh, T), dtype=torch.float32, device=dev()) for _ in range(2)]
+            a = to_np(ops.attention(q, k, v, key_mask, kv_info, d, 1.0, causal, use_mfma=3, log2_scores=True, lse=lse[0])).reshape(B, T, -1)
+            r = to_np(ops.attention(q, k, v, key_mask, kv_info, d, 1.0, causal, use_mfma=0, log2_scores=True, lse=lse[1])).reshape(B, T, -1)
+            gm = to_np(ops.attention(q, k, v, key_mask, kv_info, d, 1.0, causal, use_mfma=2, log2_scores=True)).reshape(B, T, -1)
+            auto = to_np(ops.attention(q, k, v, key_mask, kv_info, d, 1.0, causal, use_mfma=-1, log2_scores=True)).reshape(B, T, -1)
+            assert np.array_equal(auto, a)                                 # the default route for this shape IS the hand-placed kernel
+            assert np.isfinite(a).all(), (B, T, nh, nkv, d, causal)
+            assert not a[:, :, nh * d:].any()                              # pad columns up to the next multiple of 64 are zeroed
+            la, lr = to_np(lse[0]), to_np(lse[1])
+            for b in range(B):
+                rows = np.nonzero(mask[b])[0]
+                ra, rr = a[b, rows, :nh * d], r[b, rows, :nh * d]
+                assert rel(ra, rr) < 1e-2, (B, T, nh, nkv, d, causal, lens, rel(ra, rr))
+                assert rel(gm[b, rows, :nh * d], rr) < 1e-2
+                # ln sum exp: the row sums are taken over the bf16-rounded probabilities (the operand of the PV product)
+                fin = np.isfinite(lr[b][:, rows])
+                assert np.array_equal(fin, np.isfinite(la[b][:, rows]))
+                assert np.abs(la[b][:, rows][fin] - lr[b][:, rows][fin]).max() < 1e-2
+    with pytest.raises(Exception, match="hand-placed"):
+        B, T, nh, d = 1, 32, 2, 32
+        qkv = to_dev(bf16r(rnd(1, "ah.r", (B * T, 3 * nh * d), 1.0)), torch.bfloat16)
+        key_mask, kv_info, _ = ops.mask_prepare(to_dev(np.ones((B, T), dtype=np.int64)))
+        q, k, v = ops.qkv_post(qkv, to_dev(O.default_inv_freq(10000.0, d)), B, T, nh, nh, d, 1.0)
+        ops.attention(q, k, v, key_mask, kv_info, d, 1.0, False, use_mfma=3, log2_scores=True)
+
+
 def test_attention_fuzz_mfma_vs_simple(ops):
     """Random shapes / lengths / causal flags: the MFMA flash kernel (three-buffer prefetch, lazy rescale, XCD block order)
     against the straightforward fp32-softmax kernel on the same bf16 q, k, v."""

@@ -1,5 +1,7 @@
-"""Two ranks of the REAL trainer on one GPU (both processes on cuda:0, torch.distributed over gloo -- RCCL refuses two ranks
-on one device, and the pool gives one GPU): ContrastiveTrainer.forward_backward / .step with its HIP kernels AND its
+"""Two and four ranks of the REAL trainer on one GPU (all processes on cuda:0, torch.distributed over gloo -- RCCL refuses two ranks
+on one device, and the pool gives one GPU; its process guard allows at most 6 processes on the card, so the 8-rank case of
+BASELINE.json's target is covered with the oracle in place of the kernels by tests/test_distributed_gloo.py, world 8, and here by
+world 4: ranks r >= 2 already exercise the label offsets r * B_loc, the gather order and the AVG all-reduce beyond a swap): ContrastiveTrainer.forward_backward / .step with its HIP kernels AND its
 collectives (text all-gather, label offsets, flat-gradient average, one exchange per accumulation window), against the
 single-process formulation on the concatenated global batch with contrastive_num_segments = 2 (rank == segment,
 scripts/train_contrast.py:356-379).  What the CPU gloo test (tests/test_distributed_gloo.py) drives with the oracle in
@@ -43,7 +45,8 @@ if world > 1:
                               gradient_accumulation_steps=ga, column_weight=cw)
 else:
     sl = slice(0, B)
-    tr = P.ContrastiveTrainer(model, num_segments=2, output_llm_layer=2, train_mode=False, lr=1e-3, gradient_accumulation_steps=ga, column_weight=cw)
+    tr = P.ContrastiveTrainer(model, num_segments=int(os.environ.get("P2T_TEST_SEGMENTS", "2")), output_llm_layer=2, train_mode=False, lr=1e-3,
+                              gradient_accumulation_steps=ga, column_weight=cw)
 def batch(perm=None):
     idx = np.arange(B) if perm is None else perm
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx][sl] if world == 1 else a[idx][sl])).cuda()
@@ -53,7 +56,8 @@ if ga == 1:
     losses.append(float(tr.forward_backward(batch()).cpu()[0]))
 else:
     # window of two micro-batches: rows permuted WITHIN each rank's share so both formulations see the same shares
-    perm = np.concatenate([np.arange(B // 2)[::-1], B // 2 + np.arange(B // 2)[::-1]])
+    nsh = max(world, int(os.environ.get("P2T_TEST_SEGMENTS", "2")))
+    perm = np.concatenate([s0 * (B // nsh) + np.arange(B // nsh)[::-1] for s0 in range(nsh)])
     losses.append(float(tr.step(batch()).cpu()[0]))
     losses.append(float(tr.step(batch(perm)).cpu()[0]))
 g = tr.flat_g.detach().cpu().numpy().astype(np.float64)
@@ -76,13 +80,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, mode, tmp_path):
-    out = str(tmp_path / f"w{world}_{mode}.json")
+def _run(world, mode, tmp_path, segments=2):
+    out = str(tmp_path / f"w{world}_{mode}_{segments}.json")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   P2T_TEST_MODE=mode, P2T_TEST_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   P2T_TEST_MODE=mode, P2T_TEST_OUT=out, P2T_TEST_SEGMENTS=str(segments), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
@@ -99,6 +103,36 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_segmented_step(mode, tmp_
     if mode == "ga2":                          # the optimizer ran once at the end of the window: same parameters
         p2, p1 = np.array(two["p"]), np.array(one["p"])
         assert np.linalg.norm(p2 - p1) <= 1e-5 * max(np.linalg.norm(p1), 1e-12)
+
+
+@pytest.mark.parametrize("mode", ["global", "ga2"])
+def test_four_ranks_on_one_gpu_equal_the_single_process_four_segment_step(mode, tmp_path):
+    """World 4 (two pairs per rank): rank r's labels start at r * B_loc, the gathered text rows are in rank order, the flat gradient
+    is averaged over four ranks -- against ONE process with contrastive_num_segments = 4 on the same batch."""
+    four = _run(4, mode, tmp_path)
+    one = _run(1, mode, tmp_path, segments=4)
+    assert np.allclose(four["loss"], one["loss"], rtol=2e-5, atol=2e-6), (four["loss"], one["loss"])
+    g4, g1 = np.array(four["g"]), np.array(one["g"])
+    assert np.linalg.norm(g4 - g1) <= 2e-4 * max(np.linalg.norm(g1), 1e-12), (np.linalg.norm(g4 - g1), np.linalg.norm(g1))
+    if mode == "ga2":
+        p4, p1 = np.array(four["p"]), np.array(one["p"])
+        assert np.linalg.norm(p4 - p1) <= 1e-5 * max(np.linalg.norm(p1), 1e-12)
+
+
+def test_bench_py_four_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 4 --rehearse-shared-gpu --config cfg1`: bench.py's own launcher and rank logic at four ranks (the most
+    this box's process guard leaves room for): one JSON line, n_gpus 4, global batch 4 x 4, a finite loss."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse-shared-gpu", "--config", "cfg1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-batch64-check"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["value"] > 0 and "REHEARSAL" in d["data"]
+    assert d["config"]["global_batch"] == 4 * 4 and "dp4 over gloo" in d["config"]["parallelism"]
+    assert np.isfinite(d["config"]["loss"])
 
 
 def test_bench_py_two_ranks_rehearsal_on_one_gpu():
