@@ -127,6 +127,9 @@ SIGNATURES = {
     "p2t_cross_entropy_shifted_backward": (i32, [vp, i64, i32, vp, i32, i32, i32, i64, vp, vp, i64, vp]),
     "p2t_rmsnorm_backward": (i32, [vp, i64, vp, f32, vp, i64, i32, vp, i64, i64, i64, i32, vp]),
     "p2t_gather_rows_f32": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, vp]),
+    "p2t_swiglu_gu": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i32, vp]),
+    "p2t_rope_backward_pack": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "p2t_dropout_rows": (i32, [vp, i32, i64, vp, i32, i64, i64, i64, f32, u64, i32, vp]),
     "p2t_compact_rows": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "p2t_llama_prefill_workspace_bytes": (sz, [C.POINTER(LlamaConfigC), i32, i32]),
     "p2t_llama_prefill": (i32, [C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, vp, i32, i32, C.POINTER(KvCacheC), vp, vp, sz, vp]),

@@ -482,8 +482,8 @@ class LlamaTextModel(nn.Module):
         s, dt = self.spec, self.dtype
         if self.gemm_fp8:
             raise ValueError("stage-2 training runs the decoder GEMMs in the model dtype (set_gemm_dtype('model'))")
-        if s.qk_norm:
-            raise NotImplementedError("the per-head q/k RMSNorm of Qwen3 has no backward on this path yet")
+        if s.qk_norm:             # (LlamaDecoder.forward routes Qwen3 decoders to the per-layer step of p2t_hip/decoder_train.py)
+            raise NotImplementedError("the fused frozen-decoder chain has no per-head q/k RMSNorm backward: use LlamaDecoder.forward(labels=...)")
         H, F, L = s.hidden_size, s.intermediate_size, s.num_hidden_layers
         keep, layers = [], (_lib.LlamaLayerTC * L)()
         P = dict(self.named_parameters())
@@ -727,7 +727,13 @@ class LlamaDecoder(nn.Module):
         if s.hidden_size % 64:
             raise ValueError("the LM head path needs hidden_size % 64 == 0")
         L = s.num_hidden_layers
-        if labels is not None and inputs_embeds is not None and torch.is_grad_enabled() and inputs_embeds.requires_grad:
+        lora = getattr(self, "lora", None)
+        lora_live = lora is not None and any(q.requires_grad for q in lora.parameters())
+        if lora is not None and (labels is None or inputs_embeds is None):
+            raise NotImplementedError("this decoder carries LoRA adapters: only the teacher-forced LM loss (inputs_embeds + labels) runs with the "
+                                      "branches in place; merge them for inference (p2t_hip.lora.load_and_merge_adapter on peft_state_dict())")
+        if labels is not None and inputs_embeds is not None and (lora is not None or
+                                                                 (torch.is_grad_enabled() and (inputs_embeds.requires_grad or lora_live))):
             B, T, _ = inputs_embeds.shape
             if tuple(labels.shape) != (B, T):
                 raise ValueError(f"labels shape {tuple(labels.shape)} != {(B, T)}")
@@ -742,6 +748,14 @@ class LlamaDecoder(nn.Module):
                               f"({call('p2t_llama_tape_bytes', C.byref(m.ensure_engine(L)['cfg']), B, T) / 2 ** 30:.1f} GiB for this batch) and recomputes "
                               "nothing: lower the micro-batch if memory is the limit", RuntimeWarning, stacklevel=2)
                 self._warned_checkpointing = True
+            if lora is not None or s.qk_norm:
+                # LoRA branches (scripts/train_instruct.py:146-183) or Qwen3's per-head q / k norm sit between the fused blocks of
+                # p2t_llama_train_forward: the per-layer form of the same step (p2t_hip/decoder_train.py)
+                if m.gemm_fp8:
+                    raise ValueError("stage-2 training runs the decoder GEMMs in the model dtype (set_gemm_dtype('model'))")
+                from .decoder_train import lora_lm_loss
+                loss, logits = lora_lm_loss(self, lora, inputs_embeds, attention_mask, labels)
+                return CausalLMOutput(loss=loss, logits=logits)
             loss, logits = _DecoderLossFn.apply(inputs_embeds, self, attention_mask, labels)
             return CausalLMOutput(loss=loss, logits=logits[..., : s.vocab_size])
         h = m.hidden_state(input_ids, attention_mask, L) if inputs_embeds is None else m.hidden_state_from_embeds(inputs_embeds, attention_mask, L)
@@ -977,6 +991,20 @@ class Esm2LlamaInstructForCausalLM(PreTrainedModel):
                                               use_cache=False, output_attentions=False, output_hidden_states=False, return_dict=False,
                                               return_decoder_inputs=True)
         return self.llama_decoder.generate(inputs_embeds=prompt_embeds, attention_mask=prompt_mask, **kwargs)
+
+    def add_lora(self, r: int, lora_alpha: Optional[float] = None, lora_dropout: float = 0.1, target_modules=None, seed: int = 0):
+        """`get_peft_model(model, LoraConfig(r, lora_alpha = 2 r, lora_dropout = 0.1, target_modules = [...decoder projections...],
+        modules_to_save = adapter.fc1 / fc2))` of scripts/train_instruct.py:155-183, for the decoder targets (the script's ESM-C
+        target names match no module of the ESM2 encoder): trainable A / B pairs on the seven projections of every decoder layer
+        (p2t_hip/decoder_train.py), the base weights frozen, the modality adapter left trainable.  Returns the DecoderLora module
+        (its parameters are what the optimizer takes next to the adapter's)."""
+        from .decoder_train import TARGETS, DecoderLora
+        self.llama_decoder.lora = DecoderLora(self.llama_decoder, r, lora_alpha, lora_dropout, TARGETS if target_modules is None else target_modules, seed)
+        self.esm_encoder.requires_grad_(False)
+        for n, q in self.llama_decoder.named_parameters():
+            if not n.startswith("lora."):
+                q.requires_grad_(False)
+        return self.llama_decoder.lora
 
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
         """Accepted for loop compatibility (reference :253-261; `transformers.Trainer(gradient_checkpointing=True)` passes
