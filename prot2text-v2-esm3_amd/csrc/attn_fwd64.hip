@@ -119,26 +119,41 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
 
     // Persistent: one workgroup per CU walks the query blocks id = blockIdx.x, + gridDim.x, ... (a new workgroup of this size
     // starts ~2 us after its predecessor ends; gridDim.x is a multiple of 8, so a workgroup's blocks stay on its XCD's residue).
-    // PRE(block) requests the block's Q fragments and first six K / V tiles; it runs BEFORE the previous block's epilogue, whose
-    // ~1.7 us cover the flight (profiles/r04_attn64_v3_gaps.log).  MAIN(block) is the K / V loop; it leaves O^T, the row sums and
-    // the reference exponents in registers for the epilogue.
-    i32x4 dv;                     // DMA source offsets in use (asm state carried from PRE to MAIN)
-    f32x16 qa, qb;                // Q fragments, in flight between PRE and MAIN: nothing but the two statements touches them
-#define P2T_ATTN64_RUN_PRE(BK)                                                                                                          \
+    // MAIN(block) is the K / V loop; it leaves O^T, the row sums and the reference exponents in registers for the epilogue.  Its
+    // K / V stream is CONTINUOUS across blocks: the last iterations of a block, whose ring slots would sit idle, request the next
+    // block's tiles K'0..K'3 / V'0..V'2 (the twelve-piece burst a block used to open with cost its waves ~4 000 cycles of DMA issue:
+    // profiles/r04_attn64_v4_diag.log), so the next MAIN finds them in the ring at phase c0 = (tiles so far) & 3.  PREQ(block) then
+    // only requests the block's Q fragments; it runs BEFORE the previous block's epilogue, whose ~1.7 us cover their flight.  A
+    // workgroup's first block, and the successor of a block with fewer than five tiles, opens with PRE (Q + the first six tiles).
+    i32x4 dv;                     // DMA source offsets in use (asm state carried between the statements)
+    f32x16 qa, qb;                // Q fragments, in flight between PRE / PREQ and MAIN: nothing but those statements touches them
+#define P2T_ATTN64_RUN_PRE(BK, C0V)                                                                                                     \
     asm volatile(P2T_ATTN64_PRE                                                                                                         \
                  : "={v[146:149]}"(dv), "={a[64:79]}"(qa), "={a[80:95]}"(qb), "+{s[36:37]}"(BK.kptr), "+{s[38:39]}"(BK.vptr)          \
-                 : "{s[40:41]}"(BK.qptr), "{s44}"(BK.n_it), "{s45}"(s_ldsk), "{s46}"(s_seq), "{v[150:153]}"(voffs), "{v[154:157]}"(BK.misc) \
+                 : "{s[40:41]}"(BK.qptr), "{s44}"(BK.n_it), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s91}"(C0V), "{v[150:153]}"(voffs),     \
+                   "{v[154:157]}"(BK.misc)                                                                                              \
                  : P2T_ATTN64_PRE_CLOBBERS)
+#define P2T_ATTN64_RUN_PREQ(BK)                                                                                                         \
+    asm volatile(P2T_ATTN64_PREQ : "={a[64:79]}"(qa), "={a[80:95]}"(qb) : "{s[40:41]}"(BK.qptr), "{v[154:157]}"(BK.misc) : "memory")
     int id = blockIdx.x;
+    int c0 = 0, pref = 0;          // ring phase of the block's tile 0; 1 = its first tiles came through the predecessor's stream
     A64Block cur = a64_block<CAUSAL>(id, q, k, v, key_mask, kv_info, B, seq, nh, nkv, w, lane);
-    P2T_ATTN64_RUN_PRE(cur);
+    P2T_ATTN64_RUN_PRE(cur, c0);
     while (true) {
+        const int next = id + (int)gridDim.x;
+        const bool has_next = next < n_blocks;
+        A64Block nxt = cur;
+        if (has_next) nxt = a64_block<CAUSAL>(next, q, k, v, key_mask, kv_info, B, seq, nh, nkv, w, lane);
+        // the stream hands tiles over only from a block long enough to have idle slots for all of them (K'0 rides in iteration n_it - 5)
+        const int s_nitn = (has_next && cur.n_it >= 5) ? nxt.n_it : 0;
+        uint64_t knext = nxt.kptr, vnext = nxt.vptr;
         f32x16 oA0, oA1, oB0, oB1;
         float lA, lB;                 // row sums (the ones-row of the PV product: every lane holds its query's whole sum)
         f32x2 mref;
 #define P2T_ATTN64_OUTS "={a[0:15]}"(oA0), "={a[16:31]}"(oA1), "={a[32:47]}"(oB0), "={a[48:63]}"(oB1), "={a224}"(lA), "={a240}"(lB), "={v[132:133]}"(mref), \
                         "+{s[36:37]}"(cur.kptr), "+{s[38:39]}"(cur.vptr), "+{v[146:149]}"(dv)
 #define P2T_ATTN64_INS "{s[42:43]}"(cur.mptr), "{s44}"(cur.n_it), "{s45}"(s_ldsk), "{s46}"(s_seq), "{s47}"(cur.flags), "{s49}"(cur.q0), \
+                       "{s[86:87]}"(knext), "{s[88:89]}"(vnext), "{s90}"(s_nitn), "{s91}"(c0), "{s92}"(pref),                           \
                        "{v[138:141]}"(ka), "{v[142:145]}"(va), "{v[150:153]}"(voffs), "{v[154:157]}"(cur.misc), "{a[64:79]}"(qa), "{a[80:95]}"(qb)
 #ifdef P2T_LAB
         i32x4 cyc0, cyc1;
@@ -161,11 +176,20 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
 #undef P2T_ATTN64_OUTS
 #undef P2T_ATTN64_INS
         const A64Block done = cur;
-        const int next = id + (int)gridDim.x;
-        if (next < n_blocks) {
-            cur = a64_block<CAUSAL>(next, q, k, v, key_mask, kv_info, B, seq, nh, nkv, w, lane);
-            __builtin_amdgcn_s_barrier();          // every wave is done with this block's K / V ring
-            P2T_ATTN64_RUN_PRE(cur);
+        c0 = (c0 + done.n_it) & 3;
+        if (has_next) {
+            cur = nxt;
+            if (s_nitn > 0) {
+                // the first tiles of `cur` are in the ring (K'0..K'3, V'0..V'2 as far as they exist): its streams resume behind them
+                pref = 1;
+                cur.kptr += 4 * (uint64_t)kA64Slot;
+                cur.vptr += 3 * (uint64_t)kA64Slot;
+                P2T_ATTN64_RUN_PREQ(cur);
+            } else {
+                pref = 0;
+                __builtin_amdgcn_s_barrier();          // every wave is done with the previous block's K / V ring
+                P2T_ATTN64_RUN_PRE(cur, c0);
+            }
         }
 #ifdef P2T_LAB
         if constexpr (DIAG != 0) {
@@ -181,6 +205,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
                 dst[12] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);          // HW_ID (wave / simd / cu / sh / se ...)
                 dst[13] = (float)__builtin_amdgcn_s_getreg((31 << 11) | 20);                      // XCC_ID
             }
+            t_in = __builtin_amdgcn_s_memtime();          // (re-used: start of the epilogue)
         }
 #endif
         // ---- epilogue: O^T rows = channels (r & 3) + 8 (r >> 2) + 4 hh (+ 32 per d-tile), column = query ----
@@ -218,10 +243,16 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the stage is read out before the next block's epilogue rewrites it
-        if (next >= n_blocks) break;
+#ifdef P2T_LAB
+        if constexpr (DIAG != 0) {
+            if (lane == 0) lse[((int64_t)id * 4 + w) * 16 + 14] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_in);      // cycles of the epilogue
+        }
+#endif
+        if (!has_next) break;
         id = next;
     }
 #undef P2T_ATTN64_RUN_PRE
+#undef P2T_ATTN64_RUN_PREQ
 }
 
 bool attn_fwd64_eligible(int64_t ld_out, int T, int nh, int nkv, int d, int dp, int log2_scores) {

@@ -56,4 +56,5 @@ for var in variants:
                 gaps.append((rows[i, 10] - rows[i - 1, 11]) % 16777216)
     print(f"   {len(np.unique(key))} CUs; block {np.mean(durs) / 100:.2f} us, gap between blocks of a CU {np.mean(gaps) / 100:.2f} us (median {np.median(gaps) / 100:.2f}), "
           f"in-block clock {np.mean(clk):.3f} GHz, blocks per CU {len(w0) / len(np.unique(key)):.1f}")
+    print(f"   epilogue (normalise, stage through LDS, stores): {st[:, :, 14].mean():.0f} cycles per block")
     print("   per iteration: barrier %.0f setupA %.0f seg1 %.0f maskB %.0f seg2 %.0f maskA %.0f  total %.0f" % (tuple(st[:, :, i].mean() / n_it for i in (1, 2, 3, 4, 5, 6)) + (st[:, :, 1:7].sum(axis=2).mean() / n_it,)), flush=True)

@@ -76,7 +76,12 @@ LDSV, Q0, TAILT, NITM1 = 48, 49, 50, 51
 J, R, TK, TV, J1, SLK, SLKS, MFROM, TMP, TMP2, KB = 52, 53, 54, 55, 56, 57, 58, 59, 61, 62, 63
 VIS, CC, RET = 66, 68, 84                       # pairs
 ACC0, PREV, CUR = 72, 80, 82                    # diagnostic build: s72..79 cycle sums per phase, s80 previous stamp, s[82:83] s_memtime
-MAXS = 85
+# the continuous K / V stream: the NEXT block's first tiles ride in the ring slots the last iterations of this block leave idle
+KNEXT, VNEXT = 86, 88                           # pairs (inputs): the next block's K / V rows
+NITN, C0, PREF = 90, 91, 92                     # inputs: tiles of the next block to request here (0: none), ring phase of this block's
+                                                # tile 0 (cumulative tile count & 3), 1 = this block's first tiles were requested by its predecessor
+LIMV, LIMK, TAILV, TAILK, LVT, LKT = 60, 64, 65, 70, 71, 93
+MAXS = 93
 
 # knobs of the diagnostic variants (lab build): the product uses the defaults
 VAR = {"dma_gaps": (5, 15), "no_dma": False, "no_softmax": False, "no_lds": False, "no_exp": False, "no_cvtmax": False, "qk_agpr": False}
@@ -194,7 +199,7 @@ def spread(n, gaps):
 
 def segment(X, Y, kset, vset, reads, read_gaps, dma, hooks):
     """20 MFMAs on tile Y beside the softmax of tile X.  reads: 16 or 8 LDS reads spread over the gaps read_gaps = (first, end);
-    dma: {gap: (ring base sgpr, LDS byte offset, source offset vgpr, source pointer sgpr pair, tile index sgpr)};
+    dma: {gap: (ring base sgpr, LDS byte offset, source offset vgpr, source pointer sgpr pair, tile index sgpr, limit sgpr)};
     hooks: {gap: function emitting that gap's scalar bookkeeping} -- everything an iteration needs besides the softmax rides in
     MFMA gaps, the segment boundaries hold only the rescale test."""
     sx = S[X]
@@ -238,9 +243,9 @@ def segment(X, Y, kset, vset, reads, read_gaps, dma, hooks):
         if g in hooks:
             hooks[g]()
         if g in dma and not VAR["no_dma"]:
-            _, _, voff, ptr, tile = dma[g]
+            _, _, voff, ptr, tile, lim = dma[g]
             skip = lab("nodma")
-            e(f"s_cmp_lt_u32 {sr(tile)}, {sr(NIT)}")
+            e(f"s_cmp_lt_u32 {sr(tile)}, {sr(lim)}")
             e(f"s_cbranch_scc0 {skip}")
             e(f"global_load_lds_dwordx4 {vr(voff)}, {sr(ptr, 2)}")
             e(f"{skip}:")
@@ -352,38 +357,45 @@ def mask_check(Y, tile_s):
 
 
 def barrier_wait():
-    """Pieces still allowed in flight when tile pair j is needed: 2 * min(n_it - 1 - j, 4)."""
+    """Pieces still allowed in flight when tile pair j is needed = those issued behind it: V(j+1), K(j+3), V(j+2), K(j+4), two pieces
+    each, as far as they exist (this block's tiles, then the next block's first ones: LVT / LKT = total tiles of the V / K stream)."""
+    slow, bar = lab("wslow"), lab("bar")
     labs = {n: lab(f"w{n}") for n in (6, 4, 2, 0)}
-    bar = lab("bar")
-    e(f"s_sub_u32 {sr(R)}, {sr(NITM1)}, {sr(J)}")
-    e(f"s_cmp_lt_u32 {sr(R)}, 4")
-    e(f"s_cbranch_scc1 {labs[6]}")
+    e(f"s_add_u32 {sr(R)}, {sr(J)}, 2")
+    e(f"s_cmp_lt_u32 {sr(R)}, {sr(LVT)}")
+    e(f"s_cbranch_scc0 {slow}")
+    e(f"s_add_u32 {sr(R)}, {sr(J)}, 4")
+    e(f"s_cmp_lt_u32 {sr(R)}, {sr(LKT)}")
+    e(f"s_cbranch_scc0 {slow}")
     e("s_waitcnt vmcnt(8)")
     e(f"{bar}:")
     e("s_barrier")
     o = TAIL.append
-    o(f"{labs[6]}:")
-    o(f"s_cmp_eq_u32 {sr(R)}, 3")
-    o(f"s_cbranch_scc0 {labs[4]}")
-    o("s_waitcnt vmcnt(6)")
+    o(f"{slow}:")
+    o(f"s_mov_b32 {sr(R)}, 0")
+    for d, lim in ((1, LVT), (3, LKT), (2, LVT), (4, LKT)):
+        o(f"s_add_u32 {sr(TMP)}, {sr(J)}, {d}")
+        o(f"s_cmp_lt_u32 {sr(TMP)}, {sr(lim)}")
+        o(f"s_cselect_b32 {sr(TMP)}, 2, 0")
+        o(f"s_add_u32 {sr(R)}, {sr(R)}, {sr(TMP)}")
+    o(f"s_cmp_ge_u32 {sr(R)}, 8")
+    o(f"s_cbranch_scc0 {labs[6]}")
+    o("s_waitcnt vmcnt(8)")
     o(f"s_branch {bar}")
-    o(f"{labs[4]}:")
-    o(f"s_cmp_eq_u32 {sr(R)}, 2")
-    o(f"s_cbranch_scc0 {labs[2]}")
-    o("s_waitcnt vmcnt(4)")
-    o(f"s_branch {bar}")
-    o(f"{labs[2]}:")
-    o(f"s_cmp_eq_u32 {sr(R)}, 1")
-    o(f"s_cbranch_scc0 {labs[0]}")
-    o("s_waitcnt vmcnt(2)")
-    o(f"s_branch {bar}")
+    for n, nxt in ((6, 4), (4, 2), (2, 0)):
+        o(f"{labs[n]}:")
+        o(f"s_cmp_eq_u32 {sr(R)}, {n}")
+        o(f"s_cbranch_scc0 {labs[nxt]}")
+        o(f"s_waitcnt vmcnt({n})")
+        o(f"s_branch {bar}")
     o(f"{labs[0]}:")
     o("s_waitcnt vmcnt(0)")
     o(f"s_branch {bar}")
 
 
 def iteration(c, end_label):
-    """Iteration j with j = c (mod 4): reads V(j) from slot c and K(j+2) from slot c ^ 2, writes V(j+3) and K(j+5).
+    """Iteration whose tile sits at ring position c (= (C0 + j) & 3): reads V(j) from slot c and K(j+2) from slot c ^ 2, writes V(j+3)
+    and K(j+5) -- or, past this block's last tile, the next block's tiles V'(j+3-n_it) and K'(j+5-n_it), up to K'(3).
     The tile barrier sits in gap 1 of segment 1: nothing ahead of it needs tile pair j (QK_B(j) runs on fragments read an
     iteration ago, the softmax on registers)."""
     par = c & 1
@@ -397,7 +409,9 @@ def iteration(c, end_label):
 
     def tile_v():
         e(f"s_add_u32 {sr(TV)}, {sr(J)}, 3")
-        e(f"s_cmp_eq_u32 {sr(TV)}, {sr(TAILT)}")
+        e(f"s_cmp_eq_u32 {sr(TV)}, {sr(NIT)}")             # the V stream moves on to the next block's tiles
+        call("s_cbranch_scc1", SUBS["nextV"])
+        e(f"s_cmp_eq_u32 {sr(TV)}, {sr(TAILV)}")
         call("s_cbranch_scc1", SUBS["tailV"])
 
     def adv_v():
@@ -405,7 +419,7 @@ def iteration(c, end_label):
         e(f"s_addc_u32 {sr(VPTR + 1)}, {sr(VPTR + 1)}, 0")
 
     segment("A", "B", par, 1 - par, v_reads(par, c), (2, 10),
-            {g0: (LDSV, sv * SLOT, DVV, VPTR, TV), g1: (LDSV, sv * SLOT + 4096, DVV + 1, VPTR, TV)},
+            {g0: (LDSV, sv * SLOT, DVV, VPTR, TV, LIMV), g1: (LDSV, sv * SLOT + 4096, DVV + 1, VPTR, TV, LIMV)},
             {1: barrier_wait, 3: tile_v, 8: lambda: mask_check("B", J), g1 + 1: adv_v})
     stamp(3)
     e("s_waitcnt lgkmcnt(0)")
@@ -415,7 +429,9 @@ def iteration(c, end_label):
 
     def tile_k():
         e(f"s_add_u32 {sr(TK)}, {sr(J)}, 5")
-        e(f"s_cmp_eq_u32 {sr(TK)}, {sr(TAILT)}")
+        e(f"s_cmp_eq_u32 {sr(TK)}, {sr(NIT)}")
+        call("s_cbranch_scc1", SUBS["nextK"])
+        e(f"s_cmp_eq_u32 {sr(TK)}, {sr(TAILK)}")
         call("s_cbranch_scc1", SUBS["tailK"])
 
     def adv_k():
@@ -424,15 +440,14 @@ def iteration(c, end_label):
 
     def loop_ctl():
         e(f"s_add_u32 {sr(J)}, {sr(J)}, 1")
-        if c == 0:
-            e(f"s_mov_b32 {sr(SLK)}, {sr(SLKS)}")         # past the first tile: the lazy threshold
+        e(f"s_mov_b32 {sr(SLK)}, {sr(SLKS)}")             # past the first tile: the lazy threshold
 
     def loop_cmp():
         e(f"s_add_u32 {sr(J1)}, {sr(J1)}, 1")
         e(f"s_cmp_ge_u32 {sr(J)}, {sr(NIT)}")              # SCC holds until the branch behind the segment
 
     segment("B", "A", 1 - par, par, k_reads(par, c ^ 2), (0, 8),
-            {g0: (LDSK, sk * SLOT, DVK, KPTR, TK), g1: (LDSK, sk * SLOT + 4096, DVK + 1, KPTR, TK)},
+            {g0: (LDSK, sk * SLOT, DVK, KPTR, TK, LIMK), g1: (LDSK, sk * SLOT + 4096, DVK + 1, KPTR, TK, LIMK)},
             {2: tile_k, 8: lambda: mask_check("A", J1), g1 + 1: adv_k, 18: loop_ctl, 19: loop_cmp})
     stamp(5)
     if DIAG[0]:
@@ -441,15 +456,19 @@ def iteration(c, end_label):
 
 
 def tile_dma(kind, tile):
-    """Prologue form of one tile's two pieces (slot = tile & 3), skipped past the last tile."""
+    """Prologue form of one tile's two pieces (ring slot (C0 + tile) & 3), skipped past the last tile."""
     ptr, base, dv = (KPTR, LDSK, DVK) if kind == "K" else (VPTR, LDSV, DVV)
     skip = lab("nopro")
     e(f"s_cmp_le_u32 {sr(NIT)}, {tile}")
     e(f"s_cbranch_scc1 {skip}")
     e(f"s_cmp_eq_u32 {sr(TAILT)}, {tile}")
     call("s_cbranch_scc1", SUBS["tail" + kind])
+    e(f"s_add_u32 {sr(TMP2)}, {sr(C0)}, {tile}")
+    e(f"s_and_b32 {sr(TMP2)}, {sr(TMP2)}, 3")
+    e(f"s_lshl_b32 {sr(TMP2)}, {sr(TMP2)}, 13")
+    e(f"s_add_u32 {sr(TMP2)}, {sr(TMP2)}, {sr(base)}")
     for p in range(2):
-        e(f"s_add_u32 m0, {sr(base)}, {(tile & 3) * SLOT + p * 4096}")
+        e(f"s_add_u32 m0, {sr(TMP2)}, {p * 4096}")
         e("s_nop 0")
         e(f"global_load_lds_dwordx4 {vr(dv + p)}, {sr(ptr, 2)}")
     e(f"{skip}:")
@@ -457,33 +476,39 @@ def tile_dma(kind, tile):
     e(f"s_addc_u32 {sr(ptr + 1)}, {sr(ptr + 1)}, 0")
 
 
-def pre_body():
-    """The PRE statement: a block's Q fragments and its first six K / V tiles are requested BEFORE the previous block's epilogue
-    runs, so their flight is hidden under it (and, for the first block, under the index arithmetic of the kernel's entry).
-    Leaves: Q in a[64:95] (in flight), the DMA offsets in use in v146..149, KPTR / VPTR advanced past the tiles issued."""
+def q_loads():
+    for X in "AB":
+        for kk in range(4):
+            e(f"global_load_dwordx4 {ar(Q[X] + 4 * kk, 4)}, {vr(QOFF[X])}, {sr(QPTR, 2)} offset:{32 * kk}")
+
+
+def pre_body(full=True):
+    """The PRE statement (a workgroup's first block, and any block whose predecessor was too short to request its tiles): the
+    block's Q fragments and its first six K / V tiles are requested BEFORE the previous block's epilogue runs, so their flight is
+    hidden under it.  full = False (PREQ): the Q fragments only -- the tiles came in through the predecessor's K / V stream.
+    Leaves: Q in a[64:95] (in flight); full: the DMA offsets in use in v146..149, KPTR / VPTR advanced past the tiles issued."""
     del L[:]
     del TAIL[:]
     for k in ("tailK", "tailV"):
         SUBS[k] = lab(k)
     done = lab("predone")
-    e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
-    e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
-    for i in range(2):
-        e(f"v_mov_b32 {vr(DVK + i)}, {vr(VOFF + i)}")
-        e(f"v_mov_b32 {vr(DVV + i)}, {vr(VOFF + i)}")
     # Q fragments first (vmcnt completes in order: any wait that covers a K/V piece covers them)
-    for X in "AB":
-        for kk in range(4):
-            e(f"global_load_dwordx4 {ar(Q[X] + 4 * kk, 4)}, {vr(QOFF[X])}, {sr(QPTR, 2)} offset:{32 * kk}")
-    # K0 K1 | V0 K2 | V1 K3
-    for kind, tile in (("K", 0), ("K", 1), ("V", 0), ("K", 2), ("V", 1), ("K", 3)):
-        tile_dma(kind, tile)
-    e(f"s_branch {done}")
-    sub_tail(SUBS["tailK"], DVK)
-    sub_tail(SUBS["tailV"], DVV)
-    for x in TAIL:
-        e(x)
-    e(f"{done}:")
+    q_loads()
+    if full:
+        e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
+        e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
+        for i in range(2):
+            e(f"v_mov_b32 {vr(DVK + i)}, {vr(VOFF + i)}")
+            e(f"v_mov_b32 {vr(DVV + i)}, {vr(VOFF + i)}")
+        # K0 K1 | V0 K2 | V1 K3
+        for kind, tile in (("K", 0), ("K", 1), ("V", 0), ("K", 2), ("V", 1), ("K", 3)):
+            tile_dma(kind, tile)
+        e(f"s_branch {done}")
+        sub_tail(SUBS["tailK"], DVK)
+        sub_tail(SUBS["tailV"], DVV)
+        for x in TAIL:
+            e(x)
+        e(f"{done}:")
     return list(L)
 
 
@@ -492,7 +517,21 @@ def zero16(reg, agpr):
     return f"v_mfma_f32_32x32x16_bf16 {ar(reg, 16) if agpr else vr(reg, 16)}, {z}, {z}, 0"
 
 
-def prologue(causal):
+def sub_next(name, kind):
+    """Subroutine: the stream of `kind` moves on to the next block's tiles (its pointer, the plain DMA offsets, the stream's limit and
+    the index of its tail tile)."""
+    ptr, nxt, dv, lim, tot, tail = (KPTR, KNEXT, DVK, LIMK, LKT, TAILK) if kind == "K" else (VPTR, VNEXT, DVV, LIMV, LVT, TAILV)
+    o = TAIL.append
+    o(f"{name}:")
+    o(f"s_mov_b64 {sr(ptr, 2)}, {sr(nxt, 2)}")
+    o(f"v_mov_b32 {vr(dv)}, {vr(VOFF)}")
+    o(f"v_mov_b32 {vr(dv + 1)}, {vr(VOFF + 1)}")
+    o(f"s_mov_b32 {sr(lim)}, {sr(tot)}")
+    o(f"s_add_u32 {sr(tail)}, {sr(NIT)}, {sr(TAILT)}")
+    o(f"s_setpc_b64 {sr(RET, 2)}")
+
+
+def prologue(causal, entries):
     fin0 = lab("fin0")
     if DIAG[0]:
         for k in range(8):
@@ -503,6 +542,15 @@ def prologue(causal):
     e(f"s_sub_u32 {sr(NITM1)}, {sr(NIT)}, 1")
     e(f"s_lshr_b32 {sr(TAILT)}, {sr(SEQ)}, 6")
     e(f"s_add_u32 {sr(LDSV)}, {sr(LDSK)}, {NS * SLOT}")
+    # the two streams: this block's tiles, then up to V'(2) / K'(3) of the next block
+    e(f"s_mov_b32 {sr(LIMV)}, {sr(NIT)}")
+    e(f"s_mov_b32 {sr(LIMK)}, {sr(NIT)}")
+    e(f"s_mov_b32 {sr(TAILV)}, {sr(TAILT)}")
+    e(f"s_mov_b32 {sr(TAILK)}, {sr(TAILT)}")
+    e(f"s_min_u32 {sr(LVT)}, {sr(NITN)}, 3")
+    e(f"s_add_u32 {sr(LVT)}, {sr(LVT)}, {sr(NIT)}")
+    e(f"s_min_u32 {sr(LKT)}, {sr(NITN)}, 4")
+    e(f"s_add_u32 {sr(LKT)}, {sr(LKT)}, {sr(NIT)}")
     # lane constants
     e(f"v_mbcnt_lo_u32_b32 {vr(LANE)}, -1, 0")
     e(f"v_mbcnt_hi_u32_b32 {vr(LANE)}, -1, {vr(LANE)}")
@@ -519,8 +567,6 @@ def prologue(causal):
         for dt in range(2):
             e(zero16(O[X][dt], True))
         e(zero16(LACC[X], True))
-    e(zero16(VF(1, 0, 0), True))
-    e(zero16(VF(1, 1, 0), True))
     for X in "AB":
         e(f"v_mov_b32 {vr(MREF[X])}, 0")
         e(f"v_mov_b32 {vr(SEEN[X])}, 0")
@@ -540,33 +586,60 @@ def prologue(causal):
         e(f"s_min_u32 {sr(MFROM)}, {sr(MFROM)}, {sr(TMP)}")
     e(f"s_cmp_eq_u32 {sr(NIT)}, 0")
     e(f"s_cbranch_scc1 {fin0}")
-    # the PRE statement issued Q, K0 K1 | V0 K2 | V1 K3; behind K1 at most 8 pieces (and the previous block's stores) are in flight
-    w8, wb = lab("pw8"), lab("pwb")
+    # K(0), K(1) have landed.  Issue order behind K1 -- PRE: [Q first] K0 K1 | V0 K2 V1 K3 (8 pieces); a predecessor's stream:
+    # K'0 K'1 | V'0 K'2 V'1 K'3 V'2 (10 pieces), then the 8 Q loads of PREQ (and the predecessor's epilogue stores, which only make
+    # the counted wait err on the safe side)
+    short, pre, wb, pz = lab("pshort"), lab("ppre"), lab("pwb"), lab("pz")
     e(f"s_cmp_ge_u32 {sr(NIT)}, 4")
-    e(f"s_cbranch_scc1 {w8}")
-    e("s_waitcnt vmcnt(0)")
+    e(f"s_cbranch_scc0 {short}")
+    e(f"s_cmp_eq_u32 {sr(PREF)}, 0")
+    e(f"s_cbranch_scc1 {pre}")
+    e("s_waitcnt vmcnt(18)")
     e(f"s_branch {wb}")
-    e(f"{w8}:")
+    e(f"{pre}:")
     e("s_waitcnt vmcnt(8)")
+    e(f"s_branch {wb}")
+    e(f"{short}:")
+    e(f"s_cmp_eq_u32 {sr(PREF)}, 0")
+    e(f"s_cbranch_scc1 {pz}")
+    e("s_waitcnt vmcnt(8)")
+    e(f"s_branch {wb}")
+    e(f"{pz}:")
+    e("s_waitcnt vmcnt(0)")
     e(f"{wb}:")
     e("s_barrier")
-    # K(0) -> set 0, K(1) -> set 1
-    for st in range(2):
-        for i in k_reads(st, st):
+    # by ring phase: K(0) sits in slot C0 and goes to fragment set C0 & 1
+    pro = [lab(f"pro{c}") for c in range(4)]
+    for c in range(1, 4):
+        e(f"s_cmp_eq_u32 {sr(C0)}, {c}")
+        e(f"s_cbranch_scc1 {pro[c]}")
+    for c in range(4):
+        e(f"{pro[c]}:")
+        for i in k_reads(c & 1, c) + k_reads((c + 1) & 1, (c + 1) & 3):
             e(i)
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_barrier")                                   # every wave has K(0) in registers: slot 0 may take K(4)
-    tile_dma("V", 2)
-    tile_dma("K", 4)
-    for i in range(8):
-        e(mfma_qk("A", 0, i))
-    e("s_nop 15")
-    e(f"s_mov_b32 {sr(J)}, 0")
-    e(f"s_mov_b32 {sr(J1)}, 1")
-    mask_check("A", J)
-    for i in max_chain("A"):
-        e(i)
-    stamp(0)
+        e(zero16(VF(1 - (c & 1), 0, 0), True))       # the V fragments of "tile -1": PV_B(-1) adds 0 x 0
+        e(zero16(VF(1 - (c & 1), 1, 0), True))
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")                               # every wave has K(0) in registers: its slot may take K(4)
+        nopref, k4 = lab("nopref"), lab("k4")
+        e(f"s_cmp_eq_u32 {sr(PREF)}, 0")
+        e(f"s_cbranch_scc1 {nopref}")
+        e("s_waitcnt vmcnt(0)")                      # the Q fragments of PREQ (behind the stream's pieces, ahead of nothing this wave needs)
+        e(f"s_branch {k4}")
+        e(f"{nopref}:")
+        tile_dma("V", 2)
+        e(f"{k4}:")
+        tile_dma("K", 4)
+        for i in range(8):
+            e(mfma_qk("A", c & 1, i))
+        e("s_nop 15")
+        e(f"s_mov_b32 {sr(J)}, 0")
+        e(f"s_mov_b32 {sr(J1)}, 1")
+        mask_check("A", J)
+        for i in max_chain("A"):
+            e(i)
+        stamp(0)
+        e(f"s_branch {entries[c]}")
     return fin0
 
 
@@ -574,14 +647,15 @@ def body(causal, diag=False):
     del L[:]
     del TAIL[:]
     DIAG[0] = diag
-    for k in ("slowA", "slowB", "maskA", "maskB", "tailK", "tailV"):
+    for k in ("slowA", "slowB", "maskA", "maskB", "tailK", "tailV", "nextK", "nextV"):
         SUBS[k] = lab(k)
-    fin0 = prologue(causal)
-    loop, ends, fin, done = lab("loop"), [lab("end0"), lab("end1")], lab("fin"), lab("done")
-    e(f"{loop}:")
+    entries = [lab(f"entry{c}") for c in range(4)]
+    fin0 = prologue(causal, entries)
+    ends, fin, done = [lab("end0"), lab("end1")], lab("fin"), lab("done")
     for c in range(4):
+        e(f"{entries[c]}:")
         iteration(c, ends[c & 1])
-    e(f"s_branch {loop}")
+    e(f"s_branch {entries[0]}")
     e(f"{ends[1]}:")
     for i in range(12):
         e(mfma_pv("B", 1, i))
@@ -590,7 +664,7 @@ def body(causal, diag=False):
     for i in range(12):
         e(mfma_pv("B", 0, i))
     e(f"{fin}:")
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_waitcnt lgkmcnt(0)")                        # (the stream's last pieces stay in flight: the next block waits for them)
     stamp(7)
     e(f"{fin0}:")
     e("s_nop 15")
@@ -602,6 +676,8 @@ def body(causal, diag=False):
     sub_mask("B", SUBS["maskB"], causal)
     sub_tail(SUBS["tailK"], DVK)
     sub_tail(SUBS["tailV"], DVV)
+    sub_next(SUBS["nextK"], "K")
+    sub_next(SUBS["nextV"], "V")
     for s in TAIL:
         e(s)
     e(f"{done}:")
@@ -612,7 +688,7 @@ def clobbers():
     pinned_v = set(range(KA, KA + 4)) | set(range(VA, VA + 4)) | set(range(DVK, DVK + 4)) | set(range(VOFF, VOFF + 4)) | set(range(154, 158)) | {132, 133}
     out = [f"v{i}" for i in range(MAXV + 1) if i not in pinned_v]
     out += [f"a{i}" for i in range(96, 256) if i not in (LACC["A"], LACC["B"])]
-    out += [f"s{i}" for i in range(MAXS + 1) if (i >= 52 and not 72 <= i <= 83) or i in (TAILT, NITM1, LDSV)]
+    out += [f"s{i}" for i in range(MAXS + 1) if (i >= 52 and not 72 <= i <= 83 and not 86 <= i <= 92) or i in (TAILT, NITM1, LDSV)]
     out += ["vcc", "scc", "memory"]
     return out
 
@@ -641,8 +717,9 @@ def main():
         n_mfma = sum(1 for s in lines if s.startswith("v_mfma"))
         print(f"causal={causal}: {len(lines)} lines, {n_mfma} MFMAs")
     parts.append("#define P2T_ATTN64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
-    parts.append(emit_macro("P2T_ATTN64_PRE", pre_body()))
-    parts.append('#define P2T_ATTN64_PRE_CLOBBERS "s48", "s50", "s54", "s61", "s84", "s85", "vcc", "scc", "memory"\n')
+    parts.append(emit_macro("P2T_ATTN64_PRE", pre_body(True)))
+    parts.append(emit_macro("P2T_ATTN64_PREQ", pre_body(False)))
+    parts.append('#define P2T_ATTN64_PRE_CLOBBERS "s48", "s50", "s54", "s61", "s62", "s84", "s85", "vcc", "scc", "memory"\n')
     # diagnostic builds (lab library only): per-phase cycle sums in s70..s77, returned as outputs; variants 2.. are ablations
     # (their results are wrong by construction: what they measure is what the removed part costs)
     parts.append("#ifdef P2T_LAB\n")
