@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const bf16_t* __rest
 #define P2T_ATTN64_DIAG(N)                                                                                                                    \
             if constexpr (DIAG == N)                                                                                                              \
                 asm volatile(P2T_ATTN64_BODY_DIAG##N : P2T_ATTN64_OUTS, "={s[72:75]}"(cyc0), "={s[76:79]}"(cyc1) : P2T_ATTN64_INS : P2T_ATTN64_CLOBBERS_DIAG);
-            P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8)
+            P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8) P2T_ATTN64_DIAG(9)
 #undef P2T_ATTN64_DIAG
         } else
 #endif
@@ -277,7 +277,7 @@ int launch_attn_fwd64(const void* q, const void* k, const void* v, const uint8_t
         if (causal - 1 == N)                                                                                                                   \
             attn_fwd64_kernel<false, N><<<grid, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_mask, kv_info, (bf16_t*)out, \
                                                              ld_out, B, T, nh, nkv, d, out_cols, lse, n_blocks);
-        P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8)
+        P2T_ATTN64_DIAG(1) P2T_ATTN64_DIAG(2) P2T_ATTN64_DIAG(3) P2T_ATTN64_DIAG(4) P2T_ATTN64_DIAG(5) P2T_ATTN64_DIAG(6) P2T_ATTN64_DIAG(7) P2T_ATTN64_DIAG(8) P2T_ATTN64_DIAG(9)
 #undef P2T_ATTN64_DIAG
         P2T_LAUNCH_CHECK();
         return P2T_OK;

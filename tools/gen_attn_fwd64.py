@@ -84,7 +84,7 @@ LIMV, LIMK, TAILV, TAILK, LVT, LKT = 60, 64, 65, 70, 71, 93
 MAXS = 93
 
 # knobs of the diagnostic variants (lab build): the product uses the defaults
-VAR = {"dma_gaps": (5, 15), "no_dma": False, "no_softmax": False, "no_lds": False, "no_exp": False, "no_cvtmax": False, "qk_agpr": False}
+VAR = {"dma_gaps": (5, 15), "no_dma": False, "no_softmax": False, "no_lds": False, "no_exp": False, "no_cvtmax": False, "qk_agpr": False, "dma_form": "lds"}
 
 L = []
 TAIL = []                   # out-of-line code, emitted after the main stream
@@ -247,7 +247,15 @@ def segment(X, Y, kset, vset, reads, read_gaps, dma, hooks):
             skip = lab("nodma")
             e(f"s_cmp_lt_u32 {sr(tile)}, {sr(lim)}")
             e(f"s_cbranch_scc0 {skip}")
-            e(f"global_load_lds_dwordx4 {vr(voff)}, {sr(ptr, 2)}")
+            if VAR["dma_form"] == "lds":
+                e(f"global_load_lds_dwordx4 {vr(voff)}, {sr(ptr, 2)}")
+            else:
+                # timing experiments (wrong results): what a register-staged piece would cost the issuing wave --
+                # "reg": the plain load alone; "reg+write": plus the 16-byte LDS store of a piece loaded earlier
+                e(f"global_load_dwordx4 {vr(T[4], 4)}, {vr(voff)}, {sr(ptr, 2)}")
+                if VAR["dma_form"] == "reg+write":
+                    e(f"v_lshlrev_b32 {vr(T[3])}, 4, {vr(LANE)}")
+                    e(f"ds_write_b128 {vr(T[3])}, {vr(T[4], 4)} offset:64512")
             e(f"{skip}:")
     assert done_exp == 32 and done_max == 16 and not reads
     while done_cvt < 16:
@@ -705,7 +713,8 @@ DIAG_VARIANTS = [
     {"no_softmax": True},                           # 5: MFMA + LDS + DMA only
     {"qk_agpr": True},                              # 6: QK^T results written to AGPRs (does a VGPR-destination MFMA slow the VALU?)
     {"no_dma": True, "no_softmax": True, "no_lds": True},   # 7: bare MFMA stream
-    {"dma_gaps": (12, 17)},                         # 8
+    {"dma_form": "reg"},                            # 8: plain global_load_dwordx4 in place of the LDS-DMA piece (timing only)
+    {"dma_form": "reg+write"},                      # 9: ... plus a ds_write_b128 per piece (timing only)
 ]
 
 
