@@ -209,7 +209,7 @@ def kernel_src_sha16():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -32,14 +32,14 @@ def kernel_src_sha16():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
 FAMILIES = {"gemm_nt_mfma": "gemm_nt_mfma*", "gemm_nt_w4": "gemm_nt_mfma*",     # one family: the bf16 MFMA GEMM in its eight- and four-wave forms
-            "gemm_nt_fp8": "gemm_nt_fp8*", "attn_mfma_kernel": "attn_mfma_kernel", "norm_kernel": "norm_kernel",
+            "gemm_nt_fp8": "gemm_nt_fp8*", "attn_mfma_kernel": "attn_mfma_kernel", "attn_fwd64_kernel": "attn_fwd64_kernel", "norm_kernel": "norm_kernel",
             "gemm_skinny_kernel": "gemm_skinny_kernel", "attn_decode_mfma_kernel": "attn_decode_mfma_kernel"}   # the decode step (generate)
 
 
