@@ -128,12 +128,42 @@ template <typename Tout> __device__ __forceinline__ float gelu_erf_for(float x) 
     if constexpr (sizeof(Tout) == 2) return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
     else return gelu_erf(x);
 }
+// the same arithmetic on a pair of elements: the four Horner steps, the products and the final scaling become packed-fp32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32: two elements per issue); rcp / exp stay one per element.  `scale` multiplies the result
+// (the e4m3 epilogue's 2^-(E - 127)).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_as_x2(f32x2 x, float scale) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    const f32x2 az = __builtin_elementwise_abs(z);
+    f32x2 t;
+    t.x = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az.x, 1.0f));
+    t.y = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az.y, 1.0f));
+    f32x2 p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f32x2 w = z * 1.2011224087864498f;              // sqrt(log2 e): exp(-z^2) = exp2(-(w^2)), one packed product less
+    const f32x2 a = -(w * w);
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(a.x);
+    e.y = __builtin_amdgcn_exp2f(a.y);
+    f32x2 r = 1.0f - p * t * e;
+    r.x = copysignf(r.x, z.x);
+    r.y = copysignf(r.y, z.y);
+    return (x * (0.5f * scale)) * (1.0f + r);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
     return cdf + x * pdf;
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// where the result is rounded to bf16: hardware exp2 / rcp (1 ulp each) instead of expf's range handling and the IEEE division
+// (5 instructions instead of ~20 per element)
+template <typename Tout> __device__ __forceinline__ float silu_for(float x) {
+    if constexpr (sizeof(Tout) == 2) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    else return silu(x);
+}
 
 // counter hash shared with p2t_hip/synth.py (splitmix64 finaliser)
 __device__ __host__ __forceinline__ uint64_t mix64(uint64_t x) {

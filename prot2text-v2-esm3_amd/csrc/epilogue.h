@@ -163,9 +163,12 @@ struct EpiGeluFp8 {
         uint8_t* o = (uint8_t*)p.out + m * p.ldc + n;
         if (IN || n < p.N) {
             const float inv = __uint_as_float((unsigned)(254 - (int)p.row_scale[m]) << 23);      // 2^-(E - 127), exact
-            float r[W];
+            float r[W];      // e4m3 keeps 3 mantissa bits: the 1.5e-7 erf of the bf16 epilogue is ample (erff: 2.5 x the instructions)
 #pragma unroll
-            for (int j = 0; j < W; ++j) r[j] = gelu_erf(v[j] + b[j]) * inv;
+            for (int j = 0; j < W; j += 2) {
+                const f32x2 g = gelu_erf_as_x2(f32x2{v[j] + b[j], v[j + 1] + b[j + 1]}, inv);
+                r[j] = g.x; r[j + 1] = g.y;
+            }
             *reinterpret_cast<uint2*>(o) = make_uint2(epi_pack_fp8x4(r[0], r[1], r[2], r[3]), epi_pack_fp8x4(r[4], r[5], r[6], r[7]));
         } else if (n < p.n_zero) {
             *reinterpret_cast<uint2*>(o) = make_uint2(0u, 0u);
@@ -267,7 +270,7 @@ struct EpiSwiglu {
         float r[W];
         if (IN || n < p.N) {
 #pragma unroll
-            for (int j = 0; j < W; ++j) r[j] = silu(g[j]) * u[j];
+            for (int j = 0; j < W; ++j) r[j] = silu_for<Tout>(g[j]) * u[j];
             storeW<W>(o, r);
         } else if (f < p.n_zero) {
             zeroW<W>(r);
@@ -286,10 +289,25 @@ template <typename Tout>
 struct EpiQkvRope {
     static constexpr bool kRmw = false;
     static constexpr int kMinOps = 2 * kStoreOps8<Tout>;
-    template <int W, bool IN = false>
-    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
-                                                  const float (&b0)[W], const float (&b1)[W]) {
-        if (!IN && n >= p.N) return;
+    // The rotation in two parts, so that a caller can request the cos / sin rows of the NEXT row group before it stores this one
+    // (gemm_tile_common.h, tile_epilogue_pair): fetch2 = the two table loads (nothing for a V head), apply2_fetched = the rest.
+    static constexpr bool kFetch = true;
+    template <int W>
+    __device__ __forceinline__ static void fetch2(const EpiParams& p, int64_t m, int n, float (&c)[W], float (&s)[W]) {
+        const int hd = p.head_dim, half = hd >> 1;
+        const int blk = n >> 6;
+        const int head = hd == 64 ? blk : blk >> 1;
+        const int j = (hd == 64 ? 0 : 32 * (blk & 1)) + (n & 31);
+        const uint32_t mu = (uint32_t)m, sq = (uint32_t)p.seq;
+        const uint32_t b = mu / sq, t = mu - b * sq;
+        if (head < p.nh + p.nkv) {
+            loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + j, c);
+            loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + half + j, s);
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ static void apply2_fetched(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
+                                                          const float (&b0)[W], const float (&b1)[W], const float (&c)[W], const float (&s)[W]) {
         const int hd = p.head_dim, half = hd >> 1;
         const int blk = n >> 6;
         const int head = hd == 64 ? blk : blk >> 1;
@@ -305,9 +323,7 @@ struct EpiQkvRope {
         if (head < p.nh + p.nkv) {
             const bool is_q = head < p.nh;
             const float sc = is_q ? p.q_scale : 1.0f;
-            float c[W], s[W], o1[W], o2[W];
-            loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + j, c);
-            loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + half + j, s);
+            float o1[W], o2[W];
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 const float a1 = x1[e] * sc, a2 = x2[e] * sc;
@@ -323,6 +339,16 @@ struct EpiQkvRope {
             storeW<W>(dst + j, x1);
             storeW<W>(dst + half + j, x2);
         }
+    }
+    template <int W, bool IN = false>
+    __device__ __forceinline__ static void apply2(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
+                                                  const float (&b0)[W], const float (&b1)[W]) {
+        if (!IN && n >= p.N) return;
+        float c[W], s[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) c[e] = s[e] = 0.f;
+        fetch2<W>(p, m, n, c, s);
+        apply2_fetched<W>(p, m, n, v0, v1, b0, b1, c, s);
     }
 };
 

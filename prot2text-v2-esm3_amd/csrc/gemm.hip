@@ -151,8 +151,15 @@ extern "C" int p2t_prof_enable(int on) {
     return P2T_OK;
 }
 
+#ifdef P2T_LAB
+namespace p2t { void set_cu_override(int n); }
+#endif
 extern "C" int p2t_set_gemm_policy(int policy) {
 #ifdef P2T_LAB
+    if (policy >= 1000 && policy <= 1256) {          // lab: the launch policy counts (policy - 1000) compute units (0 = the device's own count)
+        p2t::set_cu_override(policy - 1000);
+        return P2T_OK;
+    }
     P2T_REQUIRE(policy == 0 || policy == 1 || policy == 2 || policy == 3 || policy == 4 || policy == 5 || policy == 6 || policy == 7 || policy == 8 || policy == 9 || policy == 10 || policy == 12 || policy == 128 || policy == 256,
                 "p2t_set_gemm_policy (lab build): unknown policy %d", policy);
 #else

@@ -240,6 +240,10 @@ static int launch_cfg8(const void* A, int64_t lda, const uint8_t* a_scale, const
 template <typename Epi>
 int launch_gemm_fp8_w4(const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M, int N,
                        int K, int n_cover, int grid, const EpiParams& ep, hipStream_t s);
+#ifdef P2T_LAB
+int launch_gemm_fp8_w4_diag(int diag, const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M,
+                            int N, int K, int n_cover, int grid, const EpiParams& ep, hipStream_t s);
+#endif
 template <typename Epi>
 constexpr bool kHasFp8W4 = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiSwiglu<bf16_t>>::value ||
                            std::is_same<Epi, EpiQkvRope<bf16_t>>::value || std::is_same<Epi, EpiGeluFp8>::value;
@@ -266,6 +270,12 @@ static int launch_shape8(const void* A, int64_t lda, const uint8_t* a_scale, con
     const int64_t tn = ceil_div(n_cover, 256), tm256 = ceil_div(M, 256), tm128 = ceil_div(M, 128);
     const double cost256 = (double)ceil_div(tm256 * tn, cus);
     const double cost128 = (double)ceil_div(tm128 * tn, cus) * 0.625 * 1.08;
+#ifdef P2T_LAB
+    if constexpr (std::is_same<Epi, EpiStore<bf16_t>>::value) {
+        if (tile >= 2001 && tile <= 2005) return launch_gemm_fp8_w4_diag(tile - 2000, A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, cus, ep, s);
+        if (tile == 2011) return launch_gemm_fp8_w4_diag(1, A, lda, a_scale, W, ldw, w_scale, M, N, K, n_cover, 64, ep, s);      // stamps, 64 workgroups only
+    }
+#endif
     if constexpr (std::is_same<Epi, EpiStore<bf16_t>>::value) {
         if (tile >= 1001 && tile <= 1003) {
             const int tiles_m = (int)tm256, tiles_n = (int)tn;

@@ -22,12 +22,24 @@
 #include "gemm_tile_common.h"
 #include "kernels.h"
 
+#ifndef P2T_F8_QKV_P
+#define P2T_F8_QKV_P 0      // cos / sin prefetch depth of the QKV epilogue: 1 costs 57 spill operations next to the 96 fragment registers
+#endif
+
 namespace p2t {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <typename Epi>
+// DIAG (lab build only; 0 in the product): 1 = s_memtime stamps around the two barriers of every step, summed per workgroup into
+// ep.z ([loop cycles, barrier-1 cycles, barrier-2 cycles, steps, loop realtime ticks, epilogue cycles, cycles between epilogue and
+// the next K loop, cycles of the first steps] as uint64); 2 = no DMA in the steady state
+// (garbage results, timing only).  Measured with them (profiles/r04_fp8w4_diag_*.log): a step takes ~2 680 cycles for 2 048 of matrix
+// work; the two barrier waits are ~80 cycles each, removing the 16 DMA pieces is worth 23-27 % -- the issue cost of the pieces, not
+// the latency of their data, is what the loop pays.  A wave-staggered issue order (slot m of a step belongs to wave (m - 8) & 3: one
+// piece per MFMA slot CU-wide, selected by scalar branches) was bit-identical and 7-19 % SLOWER: a taken branch per slot costs a
+// one-wave SIMD more than the queueing it avoids.
+template <typename Epi, int DIAG = 0>
 __global__ void __launch_bounds__(256)
     gemm_nt_fp8_w4_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ a_scale, const uint8_t* __restrict__ W,
                           int64_t ldw, const uint8_t* __restrict__ w_scale, int64_t M, int N, int K, int tiles_m, int tiles_n, int n_items,
@@ -62,6 +74,18 @@ __global__ void __launch_bounds__(256)
         w_voff[t] = (uint32_t)((int64_t)wr * ldw + c * 16);
     }
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    uint64_t d_loop = 0, d_b1 = 0, d_b2 = 0, d_steps = 0, d_real = 0, d_epi = 0, d_gap = 0, d_first = 0, t_epi_end = 0;
+    auto now = [&]() -> uint64_t {
+        uint64_t t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    auto now_real = [&]() -> uint64_t {
+        uint64_t t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
 
     const int fr = lane & 15, kg = lane >> 4;
     const uint32_t f_off = fr * 128 + ((kg ^ ((fr >> 1) & 7)) << 4);        // K bytes 16 g ..; K bytes 64 + 16 g .. at the same address ^ 64
@@ -124,7 +148,7 @@ __global__ void __launch_bounds__(256)
         constexpr int B = decltype(bufc)::value;
         constexpr bool RT = decltype(rt)::value;
         using FI = decltype(first);
-        auto piece = [&](int q) { if (!RT || more) dma1(q, B); };
+        auto piece = [&](int q) { if (DIAG != 2 && (!RT || more)) dma1(q, B); };
         // MFMA m of the step: phase A (m < 32): i = m & 3, j = m >> 2; phase B: i = 4 + (m & 3), j = (m - 32) >> 2
 #define P2T_F8_MM(Mi)                                                                                                              \
         mm(FI{}, std::integral_constant<int, ((Mi) < 32 ? ((Mi) & 3) : 4 + ((Mi) & 3))>{},            \
@@ -139,16 +163,25 @@ __global__ void __launch_bounds__(256)
         Wf[7] = frag(B, w_off + 7 * 2048); P2T_F8_SB P2T_F8_MM(3) P2T_F8_SB
         P2T_F8_MM(4) P2T_F8_MM(5) P2T_F8_MM(6) P2T_F8_MM(7)
         // every wave's reads of buffer B are done: it may be refilled (barrier 1)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (DIAG == 1) {
+            const uint64_t t0 = now();
+            asm volatile("s_barrier" ::: "memory");
+            d_b1 += now() - t0;
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         piece(0); P2T_F8_MM(8) P2T_F8_MM(9) piece(1); P2T_F8_MM(10) P2T_F8_MM(11) P2T_F8_MM(12)
         piece(2); P2T_F8_MM(13) P2T_F8_MM(14) piece(3); P2T_F8_MM(15) P2T_F8_MM(16) P2T_F8_MM(17)
         piece(4); P2T_F8_MM(18) P2T_F8_MM(19) piece(5); P2T_F8_MM(20) P2T_F8_MM(21) P2T_F8_MM(22)
         piece(6); P2T_F8_MM(23) P2T_F8_MM(24) piece(7); P2T_F8_MM(25) P2T_F8_MM(26) P2T_F8_MM(27)
         piece(8); P2T_F8_MM(28) P2T_F8_MM(29) piece(9); P2T_F8_MM(30) P2T_F8_MM(31)
         // step s+1 has landed in every wave (barrier 2); `ext`: the previous tile's epilogue operations sit between it and this step's DMA
+        uint64_t tb2 = 0;
+        if constexpr (DIAG == 1) tb2 = now();
         if (RT && !more) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else if (FI::value && ext) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kExtCount) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kIssuedBeforeWait) : "memory");
+        if constexpr (DIAG == 1) { d_b2 += now() - tb2; d_steps += 1; }
         // ---- phase B: W 0..3 of step s+1 first, then activation fragment j of step s+1 behind MFMA (7, j) ----
         P2T_F8_SB Wf[0] = frag(B ^ 1, w_off + 0 * 2048); P2T_F8_SB P2T_F8_MM(32) P2T_F8_SB
         piece(10); Wf[1] = frag(B ^ 1, w_off + 1 * 2048); P2T_F8_SB P2T_F8_MM(33) P2T_F8_SB
@@ -176,6 +209,14 @@ __global__ void __launch_bounds__(256)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
+    if constexpr (DIAG == 4 || DIAG == 5) {          // lab: start-phase skew of half of the XCDs (4) / of every other CU (5) by half a tile
+        const bool late = DIAG == 4 ? (blockIdx.x & 4) != 0 : ((blockIdx.x >> 3) & 1) != 0;
+        if (late) {
+            const uint64_t t0 = now();
+            const uint64_t wait_cycles = (uint64_t)nk * 1340;
+            while (now() - t0 < wait_cycles) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     // ---- prologue: steps 0 and 1 of the first tile, its scales, its first fragments ----
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -199,7 +240,10 @@ __global__ void __launch_bounds__(256)
     for (;;) {
         const int nxt = item + (int)gridDim.x;
         const bool has_next = nxt < n_items;
+        uint64_t tl0 = 0, tr0 = 0;
+        if constexpr (DIAG == 1) { tl0 = now(); tr0 = now_real(); if (ext) d_gap += tl0 - t_epi_end; }
         step(acc, I0{}, T{}, F{}, ext, true);
+        if constexpr (DIAG == 1) d_first += now() - tl0;
         step(acc, I1{}, F{}, F{}, false, true);
         for (int s = 2; s + 2 < nk; s += 2) {          // nk is even (K % 256 == 0) -- see the launcher
             step(acc, I0{}, F{}, F{}, false, true);
@@ -218,6 +262,8 @@ __global__ void __launch_bounds__(256)
         }
         step(acc, I0{}, F{}, T{}, false, has_next);
         step(acc, I1{}, F{}, T{}, false, has_next);    // (without a next tile its fragment reads fetch stale LDS: unused)
+        uint64_t te0 = 0;
+        if constexpr (DIAG == 1) { te0 = now(); d_loop += te0 - tl0; d_real += now_real() - tr0; }
         // the last MFMAs retire before the epilogue reads accumulators: the compiler tracks no hazards across inline asm, and it
         // would hoist the epilogue's v_accvgpr_read above a bare s_nop -- so every quad is re-defined (no code) BEHIND the wait
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
@@ -227,18 +273,29 @@ __global__ void __launch_bounds__(256)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j) asm volatile("" : "+a"(acc[h][i][j]));
+        // the next tile's scale bytes are combined BEFORE the first store of this tile: behind the stores, the wait for these sixteen
+        // loads (or for their spill slots) would drain every store of the epilogue -- vmcnt retires in order
+        int nsx[2] = {0, 0}, nsw[2] = {0, 0};
+        if (has_next) combine_scales(nraw, nsx, nsw);
         {
             int fr_e = fr, kg_e = kg;
-            asm volatile("" : "+v"(fr_e), "+v"(kg_e));
-            tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, N, m0, n0, wm, 2 * wn, fr_e, kg_e);
-            tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, N, m0, n0, wm, 2 * wn + 1, fr_e, kg_e);
+            asm volatile("" : "+v"(fr_e), "+v"(kg_e), "+v"(nsx[0]), "+v"(nsx[1]), "+v"(nsw[0]), "+v"(nsw[1]));
+            tile_epilogue_pair<MT, Epi, Epi::kRmw ? 2 : P2T_F8_QKV_P>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
+        }
+        if constexpr (DIAG == 1) {
+            t_epi_end = now();
+            d_epi += t_epi_end - te0;
+            if (!has_next && threadIdx.x == 0) {
+                uint64_t* d = (uint64_t*)ep.z + (size_t)blockIdx.x * 8;
+                d[0] = d_loop; d[1] = d_b1; d[2] = d_b2; d[3] = d_steps; d[4] = d_real; d[5] = d_epi; d[6] = d_gap; d[7] = d_first;
+            }
         }
         if (!has_next) break;
         ext = true;
         item = nxt;
         m0 = nm0;
         n0 = nn0;
-        combine_scales(nraw, sx, sw);
+        sx[0] = nsx[0]; sx[1] = nsx[1]; sw[0] = nsw[0]; sw[1] = nsw[1];
     }
 }
 
@@ -254,6 +311,25 @@ int launch_gemm_fp8_w4(const void* A, int64_t lda, const uint8_t* a_scale, const
     P2T_LAUNCH_CHECK();
     return P2T_OK;
 }
+#ifdef P2T_LAB
+// lab build: the diagnostic forms (plain bf16 store epilogue only; ep.z = uint64[8 * grid] for DIAG 1)
+int launch_gemm_fp8_w4_diag(int diag, const void* A, int64_t lda, const uint8_t* a_scale, const void* W, int64_t ldw, const uint8_t* w_scale, int64_t M,
+                            int N, int K, int n_cover, int grid, const EpiParams& ep, hipStream_t s) {
+    const int64_t items = (M / 256) * (N / 256);
+    if (M % 256 || N % 256 || n_cover != N || K % 256 || K < 512 || items < grid) return P2T_ERR_UNSUPPORTED;
+    using E = EpiStore<bf16_t>;
+    if (diag == 4)
+        gemm_nt_fp8_w4_kernel<E, 4><<<dim3((unsigned)grid), 256, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, (int)(M / 256), N / 256, (int)items, ep);
+    else if (diag == 5)
+        gemm_nt_fp8_w4_kernel<E, 5><<<dim3((unsigned)grid), 256, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, (int)(M / 256), N / 256, (int)items, ep);
+    else if (diag == 1)
+        gemm_nt_fp8_w4_kernel<E, 1><<<dim3((unsigned)grid), 256, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, (int)(M / 256), N / 256, (int)items, ep);
+    else
+        gemm_nt_fp8_w4_kernel<E, 2><<<dim3((unsigned)grid), 256, 0, s>>>((const uint8_t*)A, lda, a_scale, (const uint8_t*)W, ldw, w_scale, M, N, K, (int)(M / 256), N / 256, (int)items, ep);
+    P2T_LAUNCH_CHECK();
+    return P2T_OK;
+}
+#endif
 #define P2T_F8W4_INST(E) template int launch_gemm_fp8_w4<E>(const void*, int64_t, const uint8_t*, const void*, int64_t, const uint8_t*, int64_t, int, int, int, int, const EpiParams&, hipStream_t);
 P2T_F8W4_INST(EpiStore<bf16_t>)
 P2T_F8W4_INST(EpiResid)

@@ -502,7 +502,14 @@ constexpr double kSmallTileCost = 0.625;
 
 // Compute units of the current device (256 on MI355X; fewer on a partitioned one): the persistent grid is one block per
 // CU and the "round" arithmetic of the launch policy counts in CUs.
+#ifdef P2T_LAB
+static std::atomic<int> g_cu_override{0};       // lab build: p2t_set_gemm_policy(1000 + n) makes the launch policy count n compute units
+void set_cu_override(int n) { g_cu_override.store(n, std::memory_order_relaxed); }
+#endif
 static int cu_count() {
+#ifdef P2T_LAB
+    if (const int o = g_cu_override.load(std::memory_order_relaxed)) return o;
+#endif
     static int cached[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void skinny_finish(float (&red)[kSkWaves][NT][MT][64]
                 const int f = (n >> 6) * 32 + (n & 31);
                 float r[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) r[t] = silu(v[t]) * u[t];
+                for (int t = 0; t < 4; ++t) r[t] = silu_for<bf16_t>(v[t]) * u[t];
                 store4((bf16_t*)out + (int64_t)m * ldc + f, r);
             }
         } else {

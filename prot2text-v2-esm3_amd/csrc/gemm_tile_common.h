@@ -3,6 +3,8 @@
 // only sees the C/D fragment, dtype independent on gfx950 -- are common.
 #pragma once
 #include "common.h"
+#include <type_traits>
+
 #include "epilogue.h"
 
 namespace p2t {
@@ -82,6 +84,81 @@ __device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[4][MT], const E
             }
             Epi::template apply2<8, INTERIOR>(ep, m, nb, v0, v1, b0, b1);
         }
+    }
+}
+
+// Epilogue of BOTH 64-column halves of a four-wave kernel's 128 x 128 wave tile (tiles fully inside the output only), written so
+// that no wait inside it -- and none behind it -- drains the stores it has already issued.  vmcnt retires in order, so a wait for
+// a load that was issued AFTER a store also waits for that store's write to complete: tile_epilogue above pays that once per
+// 64-column half for the bias and once per four rows for a read-modify-write operand (measured with in-kernel stamps,
+// tools/w4_diag.py: 10 K cycles for the 32 stores of a plain bf16 tile, 47 K for the fp32 residual update, of a 86 K-cycle K loop).
+//   * the bias of both halves is fetched before the first store (one wait, in front of everything);
+//   * a read-modify-write operand is software-pipelined: the operand of group g + P is requested BEFORE the stores of group g are
+//     issued, so the wait for it (counted by the compiler: only younger operations stay outstanding) never covers a store.
+// Group g = (half h, row fragment j): the lane's row m0 + wm 128 + 16 j + fr, columns nb .. nb+7 and nb+32 .. nb+39 with
+// nb = n0 + (2 wn + h) 64 + 8 kg.  Results are bit-identical to tile_epilogue (same arithmetic per element).
+// The four accumulator quads of group (h, j) stay in their AGPRs until this point: the empty statement re-defines them (no code), so
+// the compiler cannot place their v_accvgpr_read copies any earlier.  Left alone it reads all 256 accumulators into VGPRs in front of
+// the epilogue, spills ~60 live registers (the next tile's fragments, the DMA offsets) to make room, and reloads them behind the
+// last store -- a wait that drains every store of the tile.
+template <typename Epi, typename = void> struct epi_has_fetch : std::false_type {};
+template <typename Epi> struct epi_has_fetch<Epi, std::void_t<decltype(Epi::kFetch)>> : std::true_type {};
+#define P2T_EPI_PIN_GROUP(h, j) \
+    asm volatile("" : "+a"(acc[h][0][j]), "+a"(acc[h][1][j]), "+a"(acc[h][2][j]), "+a"(acc[h][3][j])::"memory");
+template <int MT, typename Epi, int P = 4>
+__device__ __forceinline__ void tile_epilogue_pair(f32x4 (&acc)[2][4][MT], const EpiParams& ep, int64_t m0, int n0, int wm, int wn, int fr, int kg) {
+    const int nb0 = n0 + wn * 128 + kg * 8;
+    float b[2][2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[h][0][e] = b[h][1][e] = 0.f;
+    if (ep.bias) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            loadW<8>(ep.bias + nb0 + h * 64, b[h][0]);
+            loadW<8>(ep.bias + nb0 + h * 64 + 32, b[h][1]);
+        }
+    }
+    const int64_t mrow = m0 + wm * MT * 16 + fr;
+    if constexpr ((Epi::kRmw || epi_has_fetch<Epi>::value) && P > 0) {
+        constexpr int G = 2 * MT;           // P: groups in flight (16 registers each; the fp8 kernel, whose next-tile fragments hold 96 registers, uses fewer)
+        float r[P][2][8];
+        if constexpr (!Epi::kRmw) {         // a fetch may be skipped (V heads of the QKV epilogue): defined values either way
+#pragma unroll
+            for (int g = 0; g < P; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[g][0][e] = r[g][1][e] = 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < P; ++g) Epi::template fetch2<8>(ep, mrow + (g % MT) * 16, nb0 + (g / MT) * 64, r[g][0], r[g][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int h = g / MT, j = g % MT;
+            P2T_EPI_PIN_GROUP(h, j)
+            const float v0[8] = {acc[h][0][j][0], acc[h][0][j][1], acc[h][0][j][2], acc[h][0][j][3], acc[h][1][j][0], acc[h][1][j][1], acc[h][1][j][2], acc[h][1][j][3]};
+            const float v1[8] = {acc[h][2][j][0], acc[h][2][j][1], acc[h][2][j][2], acc[h][2][j][3], acc[h][3][j][0], acc[h][3][j][1], acc[h][3][j][2], acc[h][3][j][3]};
+            float s0[8], s1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s0[e] = r[g % P][0][e]; s1[e] = r[g % P][1][e]; }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + P < G) Epi::template fetch2<8>(ep, mrow + ((g + P) % MT) * 16, nb0 + ((g + P) / MT) * 64, r[g % P][0], r[g % P][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            Epi::template apply2_fetched<8>(ep, mrow + j * 16, nb0 + h * 64, v0, v1, b[h][0], b[h][1], s0, s1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                P2T_EPI_PIN_GROUP(h, j)
+                const float v0[8] = {acc[h][0][j][0], acc[h][0][j][1], acc[h][0][j][2], acc[h][0][j][3], acc[h][1][j][0], acc[h][1][j][1], acc[h][1][j][2], acc[h][1][j][3]};
+                const float v1[8] = {acc[h][2][j][0], acc[h][2][j][1], acc[h][2][j][2], acc[h][2][j][3], acc[h][3][j][0], acc[h][3][j][1], acc[h][3][j][2], acc[h][3][j][3]};
+                Epi::template apply2<8, true>(ep, mrow + j * 16, nb0 + h * 64, v0, v1, b[h][0], b[h][1]);
+                __builtin_amdgcn_sched_barrier(0);      // one group at a time: hoisting all 256 accumulator reads costs spills, and a reload behind the stores drains them
+            }
     }
 }
 

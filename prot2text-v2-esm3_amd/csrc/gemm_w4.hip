@@ -251,6 +251,16 @@ __global__ void __launch_bounds__(256)
     {
         f32x4 acc[2][4][MT];            // [64-column group of the wave][W fragment][activation fragment]
         bool ext = false;
+#ifdef P2T_LAB
+        // lab build: with ep.z set on an epilogue that does not use it, s_memtime stamps around the K loop and the epilogue of every
+        // tile, summed per workgroup into ep.z as uint64 [K-loop cycles, epilogue cycles, epilogue end -> next K loop, tiles, loop
+        // realtime ticks] (tools/w4_diag.py)
+        constexpr bool kDiagEpi = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiGelu<bf16_t, false>>::value || std::is_same<Epi, EpiResid>::value;
+        const bool diag = kDiagEpi && PERSIST && ep.z != nullptr;
+        uint64_t d_loop = 0, d_epi = 0, d_gap = 0, d_tiles = 0, d_real = 0, t_end = 0;
+        auto now = [&]() -> uint64_t { uint64_t t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
+        auto now_real = [&]() -> uint64_t { uint64_t t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
+#endif
         for (;;) {
             const int nxt = item + (int)gridDim.x;
             const bool has_next = PERSIST && nxt < n_items;
@@ -261,13 +271,19 @@ __global__ void __launch_bounds__(256)
                 nm0 = (int64_t)tm * 256;
                 nn0 = tn * 256;
             }
+#ifdef P2T_LAB
+            uint64_t t0 = 0, r0 = 0, t1 = 0;
+            if (diag) { t0 = now(); r0 = now_real(); if (ext) d_gap += t0 - t_end; }
+#endif
             k_loop(acc, nk, ext, has_next, nm0, nn0);
+#ifdef P2T_LAB
+            if (diag) { t1 = now(); d_loop += t1 - t0; d_real += now_real() - r0; d_tiles += 1; }
+#endif
             if (PERSIST) {
                 // launder the lane coordinates so the per-row output addresses are rebuilt per tile instead of being held across the K loop
                 int fr_e = fr, kg_e = kg;
                 asm volatile("" : "+v"(fr_e), "+v"(kg_e));
-                tile_epilogue<MT, Epi, true>(acc[0], ep, M, N, n_cover, m0, n0, wm, 2 * wn, fr_e, kg_e);
-                tile_epilogue<MT, Epi, true>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr_e, kg_e);
+                tile_epilogue_pair<MT, Epi>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
             } else {
                 const bool interior = m0 + 256 <= M && n0 + 256 <= N && n0 + 256 <= n_cover;
                 if (interior) {
@@ -278,6 +294,16 @@ __global__ void __launch_bounds__(256)
                     tile_epilogue<MT, Epi, false>(acc[1], ep, M, N, n_cover, m0, n0, wm, 2 * wn + 1, fr, kg);
                 }
             }
+#ifdef P2T_LAB
+            if (diag) {
+                t_end = now();
+                d_epi += t_end - t1;
+                if (!has_next && threadIdx.x == 0) {
+                    uint64_t* d = (uint64_t*)ep.z + (size_t)blockIdx.x * 8;
+                    d[0] = d_loop; d[1] = d_epi; d[2] = d_gap; d[3] = d_tiles; d[4] = d_real;
+                }
+            }
+#endif
             if (!has_next) break;
             ext = true;                                 // every wave issued at least kEpiOps operations in that epilogue
             item = nxt;

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) swiglu_gu_kernel(const T* __restrict__ gu
         if (!BWD) {
             float a[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = silu(g[j]) * u[j];
+            for (int j = 0; j < 4; ++j) a[j] = silu_for<T>(g[j]) * u[j];
             store4(out + m * ld_out + f, a);
         } else {
             float da[4], dg[4], du[4];
