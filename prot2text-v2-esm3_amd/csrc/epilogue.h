@@ -42,16 +42,21 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t idx, float p
 // 32 MB of results from evicting the operand panels out of the 4 MB L2s (measured +1 % on the GEMM average).
 typedef float p2t_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned p2t_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef P2T_STORE_PLAIN            // A/B switch: epilogue stores through the L2s (write-back) instead of streaming past them
+#define P2T_EPI_STORE(val, ptr) (*(ptr) = (val))
+#else
+#define P2T_EPI_STORE(val, ptr) __builtin_nontemporal_store(val, ptr)
+#endif
 template <int W> __device__ __forceinline__ void storeW(float* p, const float (&v)[W]) {
 #pragma unroll
     for (int c = 0; c < W; c += 4) {
-        __builtin_nontemporal_store(p2t_f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]}, reinterpret_cast<p2t_f32x4*>(p + c));
+        P2T_EPI_STORE((p2t_f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]}), reinterpret_cast<p2t_f32x4*>(p + c));
     }
 }
 template <int W> __device__ __forceinline__ void storeW(bf16_t* p, const float (&v)[W]) {
     if constexpr (W == 8) {
-        __builtin_nontemporal_store(p2t_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-                                    reinterpret_cast<p2t_u32x4*>(p));
+        P2T_EPI_STORE((p2t_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}),
+                      reinterpret_cast<p2t_u32x4*>(p));
     } else {
         *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }

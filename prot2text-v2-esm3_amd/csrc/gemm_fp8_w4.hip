@@ -22,8 +22,8 @@
 #include "gemm_tile_common.h"
 #include "kernels.h"
 
-#ifndef P2T_F8_QKV_P
-#define P2T_F8_QKV_P 0      // cos / sin prefetch depth of the QKV epilogue: 1 costs 57 spill operations next to the 96 fragment registers
+#ifndef P2T_F8_EPI_P
+#define P2T_F8_EPI_P 4      // row groups of a read-modify-write / rotary operand in flight ahead of the stores
 #endif
 
 namespace p2t {
@@ -144,8 +144,9 @@ __global__ void __launch_bounds__(256)
 
     // One K step s (buffer B = s & 1): the activation fragments and W 0..3 of the step are in registers.  FIRST: the tile's
     // accumulators start here (C = 0).  RT: the DMA of step s+2 is conditional (`more`: last two steps of a tile).
-    auto step = [&](f32x4 (&acc)[2][4][MT], auto bufc, auto first, auto rt, bool ext, bool more) {
+    auto step = [&](f32x4 (&acc)[2][4][MT], auto bufc, auto first, auto rt, bool ext, bool more, auto last) {
         constexpr int B = decltype(bufc)::value;
+        constexpr bool LAST = decltype(last)::value;
         constexpr bool RT = decltype(rt)::value;
         using FI = decltype(first);
         auto piece = [&](int q) { if (DIAG != 2 && (!RT || more)) dma1(q, B); };
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(256)
            acc[((Mi) < 32 ? 0 : 1)][(Mi) & 3][((Mi) < 32 ? ((Mi) >> 2) : (((Mi) - 32) >> 2))], Wf[((Mi) < 32 ? ((Mi) & 3) : 4 + ((Mi) & 3))],      \
            X[((Mi) < 32 ? ((Mi) >> 2) : (((Mi) - 32) >> 2))], sw[((Mi) < 32 ? 0 : 1)], sx[((Mi) < 32 ? ((Mi) >> 2) : (((Mi) - 32) >> 2)) >> 2]);
 #define P2T_F8_SB __builtin_amdgcn_sched_barrier(0);
+#define P2T_F8_NL(stmt) if constexpr (!LAST) { stmt }      // the last step of a tile leaves the next tile's fragments to load_first_fragments()
         // ---- phase A: W 4..7 of this step arrive (their registers were free since the previous step's last MFMA) ----
         Wf[4] = frag(B, w_off + 4 * 2048); P2T_F8_SB P2T_F8_MM(0) P2T_F8_SB
         Wf[5] = frag(B, w_off + 5 * 2048); P2T_F8_SB P2T_F8_MM(1) P2T_F8_SB
@@ -183,27 +185,28 @@ __global__ void __launch_bounds__(256)
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kIssuedBeforeWait) : "memory");
         if constexpr (DIAG == 1) { d_b2 += now() - tb2; d_steps += 1; }
         // ---- phase B: W 0..3 of step s+1 first, then activation fragment j of step s+1 behind MFMA (7, j) ----
-        P2T_F8_SB Wf[0] = frag(B ^ 1, w_off + 0 * 2048); P2T_F8_SB P2T_F8_MM(32) P2T_F8_SB
-        piece(10); Wf[1] = frag(B ^ 1, w_off + 1 * 2048); P2T_F8_SB P2T_F8_MM(33) P2T_F8_SB
-        Wf[2] = frag(B ^ 1, w_off + 2 * 2048); P2T_F8_SB P2T_F8_MM(34) P2T_F8_SB
-        Wf[3] = frag(B ^ 1, w_off + 3 * 2048); P2T_F8_SB P2T_F8_MM(35) P2T_F8_SB
-        X[0] = frag(B ^ 1, x_off + 0 * 2048); P2T_F8_SB
+        P2T_F8_SB P2T_F8_NL(Wf[0] = frag(B ^ 1, w_off + 0 * 2048);) P2T_F8_SB P2T_F8_MM(32) P2T_F8_SB
+        piece(10); P2T_F8_NL(Wf[1] = frag(B ^ 1, w_off + 1 * 2048);) P2T_F8_SB P2T_F8_MM(33) P2T_F8_SB
+        P2T_F8_NL(Wf[2] = frag(B ^ 1, w_off + 2 * 2048);) P2T_F8_SB P2T_F8_MM(34) P2T_F8_SB
+        P2T_F8_NL(Wf[3] = frag(B ^ 1, w_off + 3 * 2048);) P2T_F8_SB P2T_F8_MM(35) P2T_F8_SB
+        P2T_F8_NL(X[0] = frag(B ^ 1, x_off + 0 * 2048);) P2T_F8_SB
         piece(11); P2T_F8_MM(36) P2T_F8_MM(37) P2T_F8_MM(38) P2T_F8_MM(39) P2T_F8_SB
-        X[1] = frag(B ^ 1, x_off + 1 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[1] = frag(B ^ 1, x_off + 1 * 2048);) P2T_F8_SB
         piece(12); P2T_F8_MM(40) P2T_F8_MM(41) P2T_F8_MM(42) P2T_F8_MM(43) P2T_F8_SB
-        X[2] = frag(B ^ 1, x_off + 2 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[2] = frag(B ^ 1, x_off + 2 * 2048);) P2T_F8_SB
         piece(13); P2T_F8_MM(44) P2T_F8_MM(45) piece(14); P2T_F8_MM(46) P2T_F8_MM(47) P2T_F8_SB
-        X[3] = frag(B ^ 1, x_off + 3 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[3] = frag(B ^ 1, x_off + 3 * 2048);) P2T_F8_SB
         piece(15); P2T_F8_MM(48) P2T_F8_MM(49) P2T_F8_MM(50) P2T_F8_MM(51) P2T_F8_SB
-        X[4] = frag(B ^ 1, x_off + 4 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[4] = frag(B ^ 1, x_off + 4 * 2048);) P2T_F8_SB
         P2T_F8_MM(52) P2T_F8_MM(53) P2T_F8_MM(54) P2T_F8_MM(55) P2T_F8_SB
-        X[5] = frag(B ^ 1, x_off + 5 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[5] = frag(B ^ 1, x_off + 5 * 2048);) P2T_F8_SB
         P2T_F8_MM(56) P2T_F8_MM(57) P2T_F8_MM(58) P2T_F8_MM(59) P2T_F8_SB
-        X[6] = frag(B ^ 1, x_off + 6 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[6] = frag(B ^ 1, x_off + 6 * 2048);) P2T_F8_SB
         P2T_F8_MM(60) P2T_F8_MM(61) P2T_F8_MM(62) P2T_F8_MM(63) P2T_F8_SB
-        X[7] = frag(B ^ 1, x_off + 7 * 2048); P2T_F8_SB
+        P2T_F8_NL(X[7] = frag(B ^ 1, x_off + 7 * 2048);) P2T_F8_SB
 #undef P2T_F8_MM
 #undef P2T_F8_SB
+#undef P2T_F8_NL
         a_ptr += 128; w_ptr += 128;
     };
     using I0 = std::integral_constant<int, 0>;
@@ -230,10 +233,15 @@ __global__ void __launch_bounds__(256)
         combine_scales(raw, sx, sw);
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+    // W fragments 0..3 and all activation fragments of a tile's step 0 (buffer 0).  Also run BEHIND every epilogue: held across it,
+    // these 96 registers leave the epilogue too few (spills whose reloads drain its stores; no room to prefetch its operands)
+    auto load_first_fragments = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Wf[i] = frag(0, w_off + i * 2048);
+        for (int i = 0; i < 4; ++i) Wf[i] = frag(0, w_off + i * 2048);
 #pragma unroll
-    for (int j = 0; j < MT; ++j) X[j] = frag(0, x_off + j * 2048);
+        for (int j = 0; j < MT; ++j) X[j] = frag(0, x_off + j * 2048);
+    };
+    load_first_fragments();
 
     f32x4 acc[2][4][MT];                // [W fragments 0..3 / 4..7][W fragment & 3][activation fragment]
     bool ext = false;
@@ -242,12 +250,12 @@ __global__ void __launch_bounds__(256)
         const bool has_next = nxt < n_items;
         uint64_t tl0 = 0, tr0 = 0;
         if constexpr (DIAG == 1) { tl0 = now(); tr0 = now_real(); if (ext) d_gap += tl0 - t_epi_end; }
-        step(acc, I0{}, T{}, F{}, ext, true);
+        step(acc, I0{}, T{}, F{}, ext, true, F{});
         if constexpr (DIAG == 1) d_first += now() - tl0;
-        step(acc, I1{}, F{}, F{}, false, true);
+        step(acc, I1{}, F{}, F{}, false, true, F{});
         for (int s = 2; s + 2 < nk; s += 2) {          // nk is even (K % 256 == 0) -- see the launcher
-            step(acc, I0{}, F{}, F{}, false, true);
-            step(acc, I1{}, F{}, F{}, false, true);
+            step(acc, I0{}, F{}, F{}, false, true, F{});
+            step(acc, I1{}, F{}, F{}, false, true, F{});
         }
         int64_t nm0 = 0;
         int nn0 = 0;
@@ -260,8 +268,8 @@ __global__ void __launch_bounds__(256)
             w_ptr = (const char*)W + (int64_t)nn0 * ldw;
             fetch_scales(nm0, nn0, nraw);
         }
-        step(acc, I0{}, F{}, T{}, false, has_next);
-        step(acc, I1{}, F{}, T{}, false, has_next);    // (without a next tile its fragment reads fetch stale LDS: unused)
+        step(acc, I0{}, F{}, T{}, false, has_next, F{});
+        step(acc, I1{}, F{}, T{}, false, has_next, T{});     // the next tile's first fragments are read behind the epilogue
         uint64_t te0 = 0;
         if constexpr (DIAG == 1) { te0 = now(); d_loop += te0 - tl0; d_real += now_real() - tr0; }
         // the last MFMAs retire before the epilogue reads accumulators: the compiler tracks no hazards across inline asm, and it
@@ -280,7 +288,7 @@ __global__ void __launch_bounds__(256)
         {
             int fr_e = fr, kg_e = kg;
             asm volatile("" : "+v"(fr_e), "+v"(kg_e), "+v"(nsx[0]), "+v"(nsx[1]), "+v"(nsw[0]), "+v"(nsw[1]));
-            tile_epilogue_pair<MT, Epi, Epi::kRmw ? 2 : P2T_F8_QKV_P>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
+            tile_epilogue_pair<MT, Epi, P2T_F8_EPI_P>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
         }
         if constexpr (DIAG == 1) {
             t_epi_end = now();
@@ -296,6 +304,7 @@ __global__ void __launch_bounds__(256)
         m0 = nm0;
         n0 = nn0;
         sx[0] = nsx[0]; sx[1] = nsx[1]; sw[0] = nsw[0]; sw[1] = nsw[1];
+        load_first_fragments();
     }
 }
 
