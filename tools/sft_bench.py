@@ -77,6 +77,33 @@ def main():
     print(f"sft forward cfg3: B={B}, {Tp} residues, {T} decoder tokens ({n_desc} supervised): {dt * 1e3:.1f} ms/batch = {B / dt:.2f} samples/s, "
           f"{B * T / dt:.0f} decoder tokens/s, {f * B / dt / 1e12:.0f} TFLOP/s algorithmic ({f / 1e12:.2f} TF/sample: ESM {f_esm / 1e12:.2f}, "
           f"decoder + LM head {f_llama / 1e12:.2f}); loss {float(out.loss):.4f}", flush=True)
+    if "lora" in sys.argv:
+        # the reference's stage-2 recipe: LoRA (r = 16, alpha = 32, dropout 0.1) on the seven decoder projections + the adapter trainable
+        # (scripts/train_instruct.py:146-183); per-layer path of p2t_hip/decoder_train.py (correctness first, not tuned)
+        del o2, out
+        torch.cuda.empty_cache()
+        lora = model.add_lora(r=16, lora_alpha=32, lora_dropout=0.1)
+        model.train()
+
+        def lstep():
+            model.zero_grad(set_to_none=True)
+            lora.zero_grad(set_to_none=True)
+            o = model(**kw)
+            o.loss.backward()
+            return o
+        o3 = lstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            o3 = lstep()
+        torch.cuda.synchronize()
+        dt_l = (time.perf_counter() - t0) / 2
+        ga = [q.grad for q in lora.parameters() if q.grad is not None]
+        n_l = sum(q.numel() for q in lora.parameters())
+        print(f"sft LoRA train step cfg3: B={B}, r=16 on {len(ga)} of {len(list(lora.parameters()))} matrices with a gradient ({n_l / 1e6:.1f} M LoRA parameters): "
+              f"{dt_l * 1e3:.1f} ms/batch = {B / dt_l:.2f} samples/s; loss {float(o3.loss):.4f}; |grad| of the first B matrix "
+              f"{float([q.grad for n, q in lora.named_parameters() if n.endswith('B')][0].float().norm()):.3e}; "
+              f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 
 
 if __name__ == "__main__":
