@@ -149,3 +149,43 @@ def test_bench_py_two_ranks_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "REHEARSAL" in d["data"]
     assert d["config"]["global_batch"] == 2 * 32 and "gloo" in d["config"]["parallelism"]
     assert np.isfinite(d["config"]["loss"])
+
+
+RCCL_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "prot2text-v2-esm3_amd"))
+from p2t_hip import sharding
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)          # bench.py's call for N > 1
+assert dist.get_backend() == "nccl"
+x = torch.arange(8 * 16, dtype=torch.float32, device=dev).view(8, 16)
+out = torch.empty_like(x)
+w = dist.all_gather_into_tensor(out, x, async_op=True)        # sharding.gather_rows_async's collective
+w.wait()
+g = torch.full((1 << 20,), 3.0, device=dev)
+dist.all_reduce(g, op=dist.ReduceOp.AVG)                      # sharding.average_gradients' collective (RCCL averages in the collective)
+t = torch.tensor([1.5, 2.0], dtype=torch.float64, device=dev)
+dist.all_reduce(t)                                            # the epoch loop's [loss sum, batches] reduction
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(out, x) and float(g[0]) == 3.0 and t.tolist() == [1.5, 2.0]
+# the product's own wrappers on the initialised group (world 1: they must short-circuit, not call into RCCL with one rank)
+rows, first = sharding.gather_rows_async(x).wait()
+assert first == 0 and rows.data_ptr() == x.data_ptr()
+assert sharding.average_gradients(g).data_ptr() == g.data_ptr()
+dist.destroy_process_group()
+print("rccl world-1 ok")
+'''
+
+
+def test_rccl_backend_initialises_and_runs_the_trainers_collectives_at_world_1():
+    """The one RCCL configuration a one-GPU box allows: `init_process_group("nccl", device_id=...)` exactly as bench.py calls it for N > 1,
+    then the three collectives the trainer issues (async all_gather_into_tensor, all_reduce AVG, all_reduce SUM of float64) and a barrier on
+    GPU tensors.  It cannot show scaling or a multi-rank exchange; it shows that this image's RCCL accepts the calls the N > 1 path makes."""
+    port = _free_port()
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + RCCL_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, r.stdout[-3000:]
