@@ -204,7 +204,7 @@ def cpu_baseline(model, esm, llama, cfg_name, Tp, Tt, n_pairs, gpu_batch, with_c
 
 
 def kernel_src_sha16():
-    """Same stamp as tools/pmc_traffic.py: sha256 over csrc/*.hip and *.h."""
+    """Same stamp as tools/pmc_traffic.py: sha256 over csrc/*.hip, *.h and *.inc (printed in the roofline block of the JSON line)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "prot2text-v2-esm3_amd", "csrc")
@@ -448,7 +448,7 @@ def main():
                        "algorithmic_tflop_per_sample": round(f["total"] / 1e12, 4),
                        "step_tflops_per_gpu": round(step_tflops, 1), "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                        "loss": round(loss_val, 5)},
-            "roofline": {"bound": "mfma",
+            "roofline": {"bound": "mfma", "kernel_src_sha16": kernel_src_sha16(),
                          "kernel": ("gemm_nt_fp8_w4_kernel + gemm_nt_fp8_kernel (e4m3 16x16x128 block-scaled MFMA GEMM: four-wave persistent form, eight-wave per-tile form, all epilogues)" if fp8 else
                                     "gemm_nt_w4_kernel + gemm_nt_mfma*_kernel (bf16 16x16x32 MFMA GEMM: four-wave persistent form, eight-wave persistent / per-tile / split-K-tail forms, all epilogues)"),
                          "achieved": round(achieved, 1), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -44,6 +44,15 @@ if "FETCH_SIZE" in c:
     res["bytes_read_per_launch"] = 2.0 * 1024.0 * c["FETCH_SIZE"]
 if "WRITE_SIZE" in c:
     res["bytes_written_per_launch"] = 1024.0 * c["WRITE_SIZE"]
+import hashlib
+h = hashlib.sha256()                       # the stamp of bench.py / tools/pmc_traffic.py: which kernel sources these counters belong to
+src = os.path.join(os.path.dirname(os.path.abspath(d)), "..", "prot2text-v2-esm3_amd", "csrc")
+src = src if os.path.isdir(src) else os.path.join("prot2text-v2-esm3_amd", "csrc")
+for name in sorted(os.listdir(src)):
+    if name.endswith((".hip", ".h", ".inc")):
+        with open(os.path.join(src, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+res["kernel_src_sha16"] = h.hexdigest()[:16]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k not in ("counters", "source", "units")}, indent=1))
 PY
