@@ -212,13 +212,13 @@ struct EpiResid {
     static constexpr bool kRmw = true;
     static constexpr int kMinOps = 8;
     // interior tiles only: the stream values of both column groups, fetched ahead of the adds
-    template <int W>
+    template <int W, bool UNI = false>
     __device__ __forceinline__ static void fetch2(const EpiParams& p, int64_t m, int n, float (&r0)[W], float (&r1)[W]) {
         const float* o = (const float*)p.out + m * p.ldc + n;
         loadW<W>(o, r0);
         loadW<W>(o + 32, r1);
     }
-    template <int W>
+    template <int W, bool UNI = false>
     __device__ __forceinline__ static void apply2_fetched(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
                                                           const float (&b0)[W], const float (&b1)[W], float (&r0)[W], float (&r1)[W]) {
         float* o = (float*)p.out + m * p.ldc + n;
@@ -297,24 +297,29 @@ struct EpiQkvRope {
     // The rotation in two parts, so that a caller can request the cos / sin rows of the NEXT row group before it stores this one
     // (gemm_tile_common.h, tile_epilogue_pair): fetch2 = the two table loads (nothing for a V head), apply2_fetched = the rest.
     static constexpr bool kFetch = true;
-    template <int W>
+    // UNI: the caller walks whole wave tiles (tile_epilogue_pair) -- every lane of the wave is in the same 64-column block, so the head index
+    // is a scalar; and the two table loads are issued for V heads too (a valid row, never used): a branch around them lets the compiler sink
+    // the loads to their use, which is exactly the latency the caller issues them early to hide.
+    // fetch_shared: with head_dim 64 a lane's rotary channels are the same in every 64-column block, so one fetch serves both halves of a row.
+    __device__ __forceinline__ static bool fetch_shared(const EpiParams& p) { return p.head_dim == 64; }
+    template <int W, bool UNI = false>
     __device__ __forceinline__ static void fetch2(const EpiParams& p, int64_t m, int n, float (&c)[W], float (&s)[W]) {
         const int hd = p.head_dim, half = hd >> 1;
-        const int blk = n >> 6;
+        const int blk = UNI ? __builtin_amdgcn_readfirstlane(n >> 6) : n >> 6;
         const int head = hd == 64 ? blk : blk >> 1;
         const int j = (hd == 64 ? 0 : 32 * (blk & 1)) + (n & 31);
         const uint32_t mu = (uint32_t)m, sq = (uint32_t)p.seq;
         const uint32_t b = mu / sq, t = mu - b * sq;
-        if (head < p.nh + p.nkv) {
+        if (UNI || head < p.nh + p.nkv) {
             loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + j, c);
             loadW<W>(p.cs + (size_t)(t * (uint32_t)hd) + half + j, s);
         }
     }
-    template <int W>
+    template <int W, bool UNI = false>
     __device__ __forceinline__ static void apply2_fetched(const EpiParams& p, int64_t m, int n, const float (&v0)[W], const float (&v1)[W],
                                                           const float (&b0)[W], const float (&b1)[W], const float (&c)[W], const float (&s)[W]) {
         const int hd = p.head_dim, half = hd >> 1;
-        const int blk = n >> 6;
+        const int blk = UNI ? __builtin_amdgcn_readfirstlane(n >> 6) : n >> 6;
         const int head = hd == 64 ? blk : blk >> 1;
         const int j = (hd == 64 ? 0 : 32 * (blk & 1)) + (n & 31);          // rotary channel: pairs (j, j + hd/2)
         // 32-bit unsigned arithmetic (gemm_nt checks M < 2^31 and B * heads * seq < 2^31): a 64-bit division per row was a

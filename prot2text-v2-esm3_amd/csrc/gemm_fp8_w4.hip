@@ -23,7 +23,7 @@
 #include "kernels.h"
 
 #ifndef P2T_F8_EPI_P
-#define P2T_F8_EPI_P 4      // row groups of a read-modify-write / rotary operand in flight ahead of the stores
+#define P2T_F8_EPI_P 4      // row groups of a read-modify-write operand in flight ahead of the stores (rotary operands: two rows)
 #endif
 
 namespace p2t {
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256)
         {
             int fr_e = fr, kg_e = kg;
             asm volatile("" : "+v"(fr_e), "+v"(kg_e), "+v"(nsx[0]), "+v"(nsx[1]), "+v"(nsw[0]), "+v"(nsw[1]));
-            tile_epilogue_pair<MT, Epi, P2T_F8_EPI_P>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
+            tile_epilogue_pair<MT, Epi, (epi_has_fetch<Epi>::value && !Epi::kRmw) ? 2 : P2T_F8_EPI_P>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
         }
         if constexpr (DIAG == 1) {
             t_epi_end = now();

@@ -16,6 +16,9 @@
 #include "kernels.h"
 
 namespace p2t {
+#ifdef P2T_LAB
+__device__ uint64_t* g_lab_stamp_ptr = nullptr;          // lab build: see p2t_lab_set_stamp_buffer below
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -256,7 +259,9 @@ __global__ void __launch_bounds__(256)
         // tile, summed per workgroup into ep.z as uint64 [K-loop cycles, epilogue cycles, epilogue end -> next K loop, tiles, loop
         // realtime ticks] (tools/w4_diag.py)
         constexpr bool kDiagEpi = std::is_same<Epi, EpiStore<bf16_t>>::value || std::is_same<Epi, EpiGelu<bf16_t, false>>::value || std::is_same<Epi, EpiResid>::value;
-        const bool diag = kDiagEpi && PERSIST && ep.z != nullptr;
+        uint64_t* dbgp = kDiagEpi ? (uint64_t*)ep.z : nullptr;                  // stamps go to ep.z where the epilogue never touches it,
+        if (!dbgp) dbgp = g_lab_stamp_ptr;                                      // else to the pointer of p2t_lab_set_stamp_buffer (any epilogue)
+        const bool diag = PERSIST && dbgp != nullptr;
         uint64_t d_loop = 0, d_epi = 0, d_gap = 0, d_tiles = 0, d_real = 0, t_end = 0;
         auto now = [&]() -> uint64_t { uint64_t t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
         auto now_real = [&]() -> uint64_t { uint64_t t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(256)
                 // launder the lane coordinates so the per-row output addresses are rebuilt per tile instead of being held across the K loop
                 int fr_e = fr, kg_e = kg;
                 asm volatile("" : "+v"(fr_e), "+v"(kg_e));
-                tile_epilogue_pair<MT, Epi>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);
+                tile_epilogue_pair<MT, Epi, (epi_has_fetch<Epi>::value && !Epi::kRmw) ? 2 : 4>(acc, ep, m0, n0, wm, wn, fr_e, kg_e);      // rotary operands: two rows ahead (16 registers each; four cost spills)
             } else {
                 const bool interior = m0 + 256 <= M && n0 + 256 <= N && n0 + 256 <= n_cover;
                 if (interior) {
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(256)
                 t_end = now();
                 d_epi += t_end - t1;
                 if (!has_next && threadIdx.x == 0) {
-                    uint64_t* d = (uint64_t*)ep.z + (size_t)blockIdx.x * 8;
+                    uint64_t* d = dbgp + (size_t)blockIdx.x * 8;
                     d[0] = d_loop; d[1] = d_epi; d[2] = d_gap; d[3] = d_tiles; d[4] = d_real;
                 }
             }
@@ -450,3 +455,12 @@ int launch_gemm_w4(const void* A, int64_t lda, const void* W, int64_t ldw, int64
 }
 
 }  // namespace p2t
+
+#ifdef P2T_LAB
+// lab build only (tools/w4_diag.py): where the bf16 four-wave kernel writes its per-workgroup stamps when the epilogue's own z pointer cannot
+// carry them (QKV + RoPE, GELU, SwiGLU); nullptr switches the stamps off again.  uint64 [8 x workgroups].
+extern "C" int p2t_lab_set_stamp_buffer(void* ptr) {
+    uint64_t* p = (uint64_t*)ptr;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(p2t::g_lab_stamp_ptr), &p, sizeof(p));
+}
+#endif

@@ -1,5 +1,6 @@
 """Tile anatomy of the four-wave bf16 GEMM (lab build: P2T_HIP_LIB=tools/build/libp2t_lab.so): cycles in the K loop, in the
-epilogue and between the end of the epilogue and the next K loop, per tile (s_memtime stamps, median over the workgroups).
+epilogue and between the end of the epilogue and the next K loop, per tile (s_memtime stamps, median over the workgroups), for every
+epilogue type of the step (QKV + RoPE, GELU, SwiGLU through the lab build's global stamp pointer; store and residual through ep.z).
 A 64-deep stage is 128 MFMAs of 16 cycles = 2 048 matrix-pipe cycles.   python3 tools/w4_diag.py"""
 import os
 import sys
@@ -50,6 +51,32 @@ def report(name, M, N, K, t_plain, t_diag, dbg, fl):
 shapes = [("esm qkv (store)", 16384, 7680, 2560, _lib.EPI_STORE), ("esm fc1 (store)", 16384, 10240, 2560, _lib.EPI_STORE),
           ("esm o (resid)", 16384, 2560, 2560, _lib.EPI_RESID), ("esm fc2 (resid)", 16384, 2560, 10240, _lib.EPI_RESID),
           ("esm o b64 (resid)", 65536, 2560, 2560, _lib.EPI_RESID)]
+def stamped_any(name, fn, K, M, N):
+    """Epilogues that use (or have no) z: stamps through the lab build's global stamp pointer."""
+    import ctypes
+    _lib.lib.p2t_lab_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+    _lib.lib.p2t_lab_set_stamp_buffer.restype = ctypes.c_int
+    dbg = torch.zeros((256 * 8,), dtype=torch.int64, device=dev)
+    t_plain = timeit(fn)
+    assert _lib.lib.p2t_lab_set_stamp_buffer(ctypes.c_void_p(dbg.data_ptr())) == 0
+    t_diag = timeit(fn)
+    assert _lib.lib.p2t_lab_set_stamp_buffer(ctypes.c_void_p(0)) == 0
+    report(name, M, N, K, t_plain, t_diag, dbg, 2.0 * M * N * K / 1e12)
+
+
+M_, H_, F_ = 16384, 2560, 10240
+a_ = rand((M_, H_))
+wq_, bq_ = rand((3 * H_, H_), 0.05), rand((3 * H_,), 0.1, torch.float32)
+inv_ = torch.ones((32,), dtype=torch.float32, device=dev)
+stamped_any("esm qkv + rope", lambda: ops.gemm_qkv_rope(a_, wq_, bq_, inv_, 1024, 40, 40, 64, 0.125), H_, M_, 3 * H_)
+w1_, b1_ = rand((F_, H_), 0.05), rand((F_,), 0.1, torch.float32)
+o1_ = torch.empty((M_, F_), dtype=torch.bfloat16, device=dev)
+stamped_any("esm fc1 (gelu)", lambda: ops.gemm_nt(a_, w1_, b1_, epilogue=_lib.EPI_GELU, out=o1_, use_mfma=1), H_, M_, F_)
+at_, wg_ = rand((2048, 4096)), rand((28672, 4096), 0.05)
+stamped_any("llama gate/up (swiglu)", lambda: ops.gemm_nt(at_, wg_, None, epilogue=_lib.EPI_SWIGLU, use_mfma=1), 4096, 2048, 28672)
+wq2_ = rand((6144, 4096), 0.05)
+inv2_ = torch.ones((64,), dtype=torch.float32, device=dev)
+del a_, w1_, o1_, wg_
 for name, M, N, K, epi in shapes:
     assert epi in (_lib.EPI_STORE, _lib.EPI_RESID)
     a, w = rand((M, K)), rand((N, K), 0.05)
